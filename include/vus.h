@@ -1,0 +1,102 @@
+/* vus.h -- C ABI of the MI355X-native hot path of hvak/visual-underwater-slam.
+ *
+ * One shared library, libvus_hip.so (visual-underwater-slam_amd/csrc), exports every function
+ * declared here.  All pointers are DEVICE pointers (HBM) unless the name ends in `_host`.
+ * Every call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream),
+ * allocates nothing, and returns 0 on success or a negative VUS_E_* code (no exceptions cross the
+ * boundary; vus_last_error() gives the text for the calling thread).  The caller owns all buffers.
+ *
+ * The CPU oracle (oracle/vus_oracle.c, test infrastructure only) exports the same signatures with
+ * a `_cpu` suffix, host pointers and no stream argument.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *   front-end  : the external `gtsam_vio/ImageProcessorNodelet` wired in launch/stereo.launch:33-55
+ *                (parameters :37-47; fast_threshold=10 at :43, stereo_threshold=5 at :47) whose
+ *                output batch.py consumes at batch.py:29,149-154,323.
+ *   triangulate: AUV_ISAM.get_landmarks, batch.py:144-176.
+ *   BA kernels : the arithmetic behind gtsam.GenericStereoFactor3D (batch.py:300-305) and
+ *                gtsam.LevenbergMarquardtOptimizer(...).optimize() (batch.py:337).
+ */
+#ifndef VUS_H
+#define VUS_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VUS_OK 0
+#define VUS_E_INVALID (-1)   /* bad argument (null pointer, size out of range, ...) */
+#define VUS_E_HIP (-2)       /* a HIP runtime call failed */
+#define VUS_E_UNSUPPORTED (-3)
+
+#define VUS_ABI_VERSION 1
+
+/* keypoint key: ((255 - score) << 24) | (y * W + x).  Ascending key order == descending FAST
+ * score, ties in raster order.  Requires H * W <= 2^24. */
+#define VUS_KEY_POS_BITS 24
+#define VUS_KEY_POS_MASK 0x00FFFFFFu
+#define VUS_KEY_INVALID 0xFFFFFFFFu
+
+int vus_abi_version(void);
+const char* vus_last_error(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Stereo ORB front-end.  Images are uint8, row-major [n_img, H, pitch] (pitch >= W bytes).
+ * ---------------------------------------------------------------------------------------- */
+
+/* FAST-9/16 score map (Rosten & Drummond): score(y,x) = largest t such that the pixel is still a
+ * corner with strict comparisons  (= max over the 16 arcs of 9 of min(|d|) - 1), written only where
+ * score >= thr, else 0; the 3-pixel frame is 0.  score_out: uint8 [n_img, H, W]. */
+int vus_fast_score(const uint8_t* img, int n_img, int H, int W, int pitch, int thr,
+                   uint8_t* score_out, void* stream);
+
+/* 7x7 separable integer smoothing (weights VUS_BLUR_W, sum 256 per axis, replicate border,
+ * round-half-up on the 16-bit product).  out: uint8 [n_img, H, W]. */
+int vus_blur7(const uint8_t* img, int n_img, int H, int W, int pitch, uint8_t* out, void* stream);
+
+/* Fused detector: FAST score + strict 3x3 non-max suppression + border filter, candidates appended
+ * as keys (any order) to cand_keys[n_img, cand_cap]; cand_count[n_img] must be zero on entry and
+ * receives the TRUE number of candidates (may exceed cand_cap: the surplus is dropped and the caller
+ * must treat count > cand_cap as an error).  Also writes the smoothed image (as vus_blur7) to
+ * blur_out if it is non-null. */
+int vus_fast_detect(const uint8_t* img, int n_img, int H, int W, int pitch, int thr, int border,
+                    uint8_t* blur_out, uint32_t* cand_keys, int cand_cap, int* cand_count,
+                    void* stream);
+
+/* Keep the max_kp smallest keys of each image, sorted ascending.  kp_keys: [n_img, max_kp]
+ * (unused tail = VUS_KEY_INVALID); kp_count[n_img] = min(max_kp, min(cand_count, cand_cap)). */
+int vus_select_topk(const uint32_t* cand_keys, const int* cand_count, int n_img, int cand_cap,
+                    int max_kp, uint32_t* kp_keys, int* kp_count, void* stream);
+
+/* Orientation (intensity centroid over the radius-15 disc of `img`, quantised to 30 bins with
+ * integer arithmetic) and 256-bit rotated-BRIEF descriptor sampled from `blur`.
+ * desc_out: uint64 [n_img, max_kp, 4] (bit b of word w = test 64*w + b, set when I(p0) < I(p1));
+ * angle_out: uint8 [n_img, max_kp] (bin index). */
+int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
+                      const uint32_t* kp_keys, const int* kp_count, int max_kp,
+                      uint64_t* desc_out, uint8_t* angle_out, void* stream);
+
+/* Brute-force Hamming matcher over n_pairs (query set, train set) pairs; the query set of pair p
+ * is image q_index[p], the train set is image t_index[p] (indices into the [n_img, max_kp] arrays).  For every query keypoint: the train keypoint of smallest Hamming distance
+ * among those passing the gates  |yq - yt| <= max_dy  (max_dy < 0: no gate)  and
+ * min_disp <= xq - xt <= max_disp  (only when max_dy >= 0); ties -> lowest train index.
+ * No gated candidate -> idx -1, dist 512; best distance > max_dist -> idx -1, dist = that distance.
+ * idx_out / dist_out: int32 [n_pairs, max_kp]. */
+int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, const int* kp_count,
+                      int max_kp, int W, const int* q_index, const int* t_index, int n_pairs,
+                      int max_dy, int min_disp, int max_disp, int max_dist,
+                      int32_t* idx_out, int32_t* dist_out, void* stream);
+
+/* get_landmarks of batch.py:144-176, elementwise over n features (fp64):
+ *   feat [n,4] = (u0, v0, u1, v1) normalised image coordinates of the CameraMeasurement message,
+ *   cam  [8]   = (fx, fy, cx, cy, baseline, resolution_x, resolution_y, unused),
+ *   Rt   [12]  = row-major 3x3 rotation followed by translation (the TF of batch.py:45-48),
+ *   out  [n,6] = (X, Y, Z world point, uL, uR, v). */
+int vus_triangulate(const double* feat, int n, const double* cam, const double* Rt, double* out,
+                    void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VUS_H */

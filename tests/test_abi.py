@@ -1,0 +1,63 @@
+"""The C-ABI library loads and exports every symbol include/vus.h declares (no compute calls)."""
+import ctypes
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "vus.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vus_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_header_declares_entry_points():
+    names = _declared()
+    assert "vus_fast_detect" in names and "vus_hamming_match" in names and len(names) >= 9
+
+
+def test_hip_library_exports_every_declared_symbol():
+    import visual_underwater_slam_amd._lib as L
+    assert os.path.exists(L.LIB_PATH), "libvus_hip.so not built: run __graft_entry__.build()"
+    lib = ctypes.CDLL(L.LIB_PATH)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in vus.h but not exported"
+    lib.vus_abi_version.restype = ctypes.c_int
+    assert lib.vus_abi_version() == 1
+    # the python binding covers every declared compute entry point
+    L.load()
+    for name in _declared():
+        if name not in ("vus_abi_version", "vus_last_error"):
+            assert name in L.SIGNATURES, f"{name} missing from _lib.SIGNATURES"
+
+
+def test_oracle_exports_cpu_twins(oracle):
+    lib = oracle.lib()
+    for name in _declared():
+        if name in ("vus_abi_version", "vus_last_error"):
+            continue
+        assert hasattr(lib, name + "_cpu"), f"oracle lacks {name}_cpu"
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    """Argument validation happens on the host before any launch."""
+    import visual_underwater_slam_amd._lib as L
+    lib = L.load()
+    rc = lib.vus_fast_score(None, 1, 720, 1280, 1280, 10, None, None)
+    assert rc == -1 and b"null" in lib.vus_last_error()
+    rc = lib.vus_select_topk(ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 10, 100000, ctypes.c_void_p(8),
+                             ctypes.c_void_p(8), None)
+    assert rc == -1 and b"max_kp" in lib.vus_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    """oracle/ is test infrastructure: nothing under the product package may reach it."""
+    pkg = os.path.join(ROOT, "visual-underwater-slam_amd")
+    banned = ("import oracle", "from oracle", "libvus_oracle", "oracle.oracle", "_cpu(")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for b in banned:
+                    assert b not in txt, f"{f} mentions {b!r}"

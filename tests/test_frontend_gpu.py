@@ -1,0 +1,263 @@
+"""GPU parity: every front-end HIP kernel, called through the C ABI, against the CPU oracle on the
+same inputs.  Integer work -> bit-exact (candidates compare as sets: the GPU appends in any order)."""
+import numpy as np
+import pytest
+import torch
+
+from visual_underwater_slam_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(a, dtype=None):
+    t = torch.from_numpy(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.view(dtype) if t.element_size() == torch.empty((), dtype=dtype).element_size() else t.to(dtype)
+    return t.cuda()
+
+
+def _u32(t):
+    return t.cpu().numpy().view(np.uint32)
+
+
+def _call(name, *args):
+    import visual_underwater_slam_amd._lib as L
+    L.call(name, *args)
+
+
+def gpu_fast_score(img, thr):
+    import visual_underwater_slam_amd._lib as L
+    d = _dev(img)
+    n, H, W = img.shape
+    out = torch.empty((n, H, W), dtype=torch.uint8, device="cuda")
+    L.call("vus_fast_score", d.data_ptr(), n, H, W, W, thr, out.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def gpu_detect(img, thr=10, border=31, cap=32768, want_blur=True):
+    import visual_underwater_slam_amd._lib as L
+    d = _dev(img)
+    n, H, W = img.shape
+    keys = torch.full((n, cap), -1, dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(n, dtype=torch.int32, device="cuda")
+    blur = torch.empty((n, H, W), dtype=torch.uint8, device="cuda") if want_blur else None
+    L.call("vus_fast_detect", d.data_ptr(), n, H, W, W, thr, border, L.ptr(blur), keys.data_ptr(), cap,
+           cnt.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    return keys, cnt, blur
+
+
+@pytest.mark.parametrize("shape", [(7, 7), (33, 70), (96, 160), (100, 131), (720, 1280)])
+def test_fast_score_and_blur_bit_exact(gpu, oracle, shape):
+    H, W = shape
+    if H <= 720 and W <= 1280 and H >= 16:
+        img = synth.stereo_frames(2, 1, H=H, W=W)[0]
+    else:
+        img = np.random.default_rng(0).integers(0, 256, (2, H, W), dtype=np.uint8)
+    for thr in (10, 40):
+        assert np.array_equal(gpu_fast_score(img, thr), oracle.fast_score(img, thr))
+    import visual_underwater_slam_amd._lib as L
+    d = _dev(img)
+    out = torch.empty((2, H, W), dtype=torch.uint8, device="cuda")
+    L.call("vus_blur7", d.data_ptr(), 2, H, W, W, out.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.blur7(img))
+
+
+def test_fast_score_random_noise_and_pitch(gpu, oracle):
+    """Uniform noise is the densest-corner case; also exercises pitch > W."""
+    import visual_underwater_slam_amd._lib as L
+    rng = np.random.default_rng(5)
+    H, W, pitch = 75, 90, 128
+    buf = rng.integers(0, 256, (3, H, pitch), dtype=np.uint8)
+    img = np.ascontiguousarray(buf[:, :, :W])
+    d = _dev(buf)
+    out = torch.empty((3, H, W), dtype=torch.uint8, device="cuda")
+    L.call("vus_fast_score", d.data_ptr(), 3, H, W, pitch, 12, out.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), oracle.fast_score(img, 12))
+
+
+@pytest.mark.parametrize("shape,nf", [((128, 192), 3), ((720, 1280), 2)])
+def test_detect_candidate_sets_bit_exact(gpu, oracle, shape, nf):
+    H, W = shape
+    img = synth.stereo_frames(11, nf, H=H, W=W).reshape(2 * nf, H, W)
+    keys, cnt, blur = gpu_detect(img)
+    okeys, ocnt, oblur = oracle.fast_detect(img)
+    assert np.array_equal(cnt.cpu().numpy(), ocnt)
+    g = _u32(keys)
+    for n in range(2 * nf):
+        assert np.array_equal(np.sort(g[n, :ocnt[n]]), np.sort(okeys[n, :ocnt[n]]))
+    assert np.array_equal(blur.cpu().numpy(), oblur)
+
+
+def test_detect_flat_image_and_overflow(gpu, oracle):
+    flat = np.full((2, 100, 120), 50, np.uint8)
+    keys, cnt, _ = gpu_detect(flat, want_blur=False)
+    assert cnt.cpu().tolist() == [0, 0]
+    img = synth.stereo_frames(0, 1, H=256, W=256).reshape(2, 256, 256)
+    _, ocnt, _ = oracle.fast_detect(img, cand_cap=32768)
+    keys, cnt, _ = gpu_detect(img, cap=16, want_blur=False)      # far too small on purpose
+    assert np.array_equal(cnt.cpu().numpy(), ocnt)               # true count is still reported
+    assert (ocnt > 16).all()
+    okeys, _, _ = oracle.fast_detect(img)
+    g = _u32(keys)
+    for n in range(2):                                           # whatever was kept is a real key
+        assert set(g[n].tolist()) <= set(okeys[n, :ocnt[n]].tolist())
+
+
+@pytest.mark.parametrize("max_kp", [1, 37, 500, 2000, 4096])
+def test_select_topk_bit_exact(gpu, oracle, max_kp):
+    import visual_underwater_slam_amd._lib as L
+    img = synth.stereo_frames(4, 2, H=360, W=640).reshape(4, 360, 640)
+    okeys, ocnt, _ = oracle.fast_detect(img, want_blur=False)
+    ocnt2 = ocnt.copy()
+    ocnt2[3] = 20             # fewer candidates than max_kp
+    ocnt2[2] = 0              # none at all
+    rng = np.random.default_rng(2)
+    shuffled = okeys.copy()
+    for n in range(4):
+        shuffled[n, :ocnt2[n]] = rng.permutation(okeys[n, :ocnt2[n]])
+    kp = torch.empty((4, max_kp), dtype=torch.int32, device="cuda")
+    kc = torch.empty(4, dtype=torch.int32, device="cuda")
+    L.call("vus_select_topk", _dev(shuffled.view(np.int32)).data_ptr(), _dev(ocnt2).data_ptr(), 4,
+           okeys.shape[1], max_kp, kp.data_ptr(), kc.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    ekp, ekc = oracle.select_topk(okeys, ocnt2, max_kp)
+    assert np.array_equal(kc.cpu().numpy(), ekc)
+    assert np.array_equal(_u32(kp), ekp)
+
+
+def test_select_topk_many_equal_scores(gpu, oracle):
+    """All candidates share one score: the cut falls inside the raster-order tie-break."""
+    import visual_underwater_slam_amd._lib as L
+    rng = np.random.default_rng(9)
+    pos = rng.permutation(500000)[:30000].astype(np.uint32)
+    keys = ((np.uint32(255 - 77) << 24) | pos)[None]
+    cnt = np.array([30000], np.int32)
+    kp = torch.empty((1, 2000), dtype=torch.int32, device="cuda")
+    kc = torch.empty(1, dtype=torch.int32, device="cuda")
+    L.call("vus_select_topk", _dev(keys.view(np.int32)).data_ptr(), _dev(cnt).data_ptr(), 1, 30000, 2000,
+           kp.data_ptr(), kc.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    ekp, _ = oracle.select_topk(keys, cnt, 2000)
+    assert np.array_equal(_u32(kp), ekp)
+    assert np.array_equal(ekp[0] & 0xFFFFFF, np.sort(pos)[:2000])
+
+
+def _pipeline_oracle(oracle, img, max_kp):
+    keys, cnt, blur = oracle.fast_detect(img)
+    kp, kc = oracle.select_topk(keys, cnt, max_kp)
+    desc, ang = oracle.orient_rbrief(img, blur, kp, kc)
+    return kp, kc, blur, desc, ang
+
+
+@pytest.mark.parametrize("shape,max_kp", [((160, 224), 300), ((720, 1280), 2000)])
+def test_orient_rbrief_bit_exact(gpu, oracle, shape, max_kp):
+    import visual_underwater_slam_amd._lib as L
+    H, W = shape
+    img = synth.stereo_frames(20, 1, H=H, W=W).reshape(2, H, W)
+    kp, kc, blur, edesc, eang = _pipeline_oracle(oracle, img, max_kp)
+    kc2 = kc.copy()
+    kc2[1] = min(kc2[1], 5)     # mostly-empty image: unused slots must come out zeroed
+    edesc, eang = oracle.orient_rbrief(img, blur, kp, kc2)
+    desc = torch.empty((2, max_kp, 4), dtype=torch.int64, device="cuda")
+    ang = torch.empty((2, max_kp), dtype=torch.uint8, device="cuda")
+    L.call("vus_orient_rbrief", _dev(img).data_ptr(), _dev(blur).data_ptr(), 2, H, W, W,
+           _dev(kp.view(np.int32)).data_ptr(), _dev(kc2).data_ptr(), max_kp, desc.data_ptr(), ang.data_ptr(),
+           L.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(ang.cpu().numpy(), eang)
+    assert np.array_equal(desc.cpu().numpy().view(np.uint64), edesc)
+
+
+def test_orient_rbrief_keypoints_at_image_edge_are_clamped(gpu, oracle):
+    """Keys right at the border (outside the detector's own border filter) stay memory-safe and equal."""
+    import visual_underwater_slam_amd._lib as L
+    H, W = 64, 80
+    img = np.random.default_rng(4).integers(0, 256, (1, H, W), dtype=np.uint8)
+    blur = oracle.blur7(img)
+    pts = [(0, 0), (0, W - 1), (H - 1, 0), (H - 1, W - 1), (5, 40), (H - 2, 17)]
+    kp = np.array([[(100 << 24) | (y * W + x) for y, x in pts]], np.uint32)
+    kc = np.array([len(pts)], np.int32)
+    edesc, eang = oracle.orient_rbrief(img, blur, kp, kc)
+    desc = torch.empty((1, len(pts), 4), dtype=torch.int64, device="cuda")
+    ang = torch.empty((1, len(pts)), dtype=torch.uint8, device="cuda")
+    L.call("vus_orient_rbrief", _dev(img).data_ptr(), _dev(blur).data_ptr(), 1, H, W, W,
+           _dev(kp.view(np.int32)).data_ptr(), _dev(kc).data_ptr(), len(pts), desc.data_ptr(), ang.data_ptr(),
+           L.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(ang.cpu().numpy(), eang)
+    assert np.array_equal(desc.cpu().numpy().view(np.uint64), edesc)
+
+
+@pytest.mark.parametrize("gate", [(-1, 0, 0, 256), (5, 0, 128, 64), (2, -3, 40, 30)])
+def test_hamming_match_bit_exact(gpu, oracle, gate):
+    import visual_underwater_slam_amd._lib as L
+    H, W, K = 360, 640, 1500     # 1500 > one 1024-descriptor LDS tile
+    img = synth.stereo_frames(30, 2, H=H, W=W).reshape(4, H, W)
+    kp, kc, blur, desc, ang = _pipeline_oracle(oracle, img, K)
+    kc = kc.copy()
+    kc[3] = 700
+    q = np.array([0, 0, 2, 3, 1], np.int32)
+    t = np.array([1, 2, 3, 2, 1], np.int32)
+    max_dy, mind, maxd, maxdist = gate
+    eidx, edist = oracle.hamming_match(desc, kp, kc, W, q, t, max_dy, mind, maxd, maxdist)
+    idx = torch.empty((len(q), K), dtype=torch.int32, device="cuda")
+    dist = torch.empty((len(q), K), dtype=torch.int32, device="cuda")
+    L.call("vus_hamming_match", _dev(desc.view(np.int64)).data_ptr(), _dev(kp.view(np.int32)).data_ptr(),
+           _dev(kc).data_ptr(), K, W, _dev(q).data_ptr(), _dev(t).data_ptr(), len(q), max_dy, mind, maxd,
+           maxdist, idx.data_ptr(), dist.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+    assert np.array_equal(dist.cpu().numpy(), edist)
+    if max_dy < 0:
+        assert (eidx[4, :kc[1]] == np.arange(kc[1])).all()     # self-match: identity, distance 0
+        assert (edist[4, :kc[1]] == 0).all()
+
+
+def test_triangulate_matches_oracle(gpu, oracle):
+    from visual_underwater_slam_amd import frontend
+    rng = np.random.default_rng(8)
+    n = 1000
+    u0 = rng.uniform(-0.9, 0.9, n); v0 = rng.uniform(-0.9, 0.9, n)
+    feat = np.stack([u0, v0, u0 + rng.uniform(0.004, 0.06, n), v0 + rng.uniform(-1e-3, 1e-3, n)], 1)
+    cam = np.array([1827.0, 1827.5999755859375, 968.9000244140625, 561.4000244140625, 0.063, 1920, 1080, 0])
+    A = rng.normal(size=(3, 3)); Q, _ = np.linalg.qr(A)
+    Rt = np.concatenate([Q.reshape(-1), rng.normal(size=3)])
+    got = frontend.triangulate(_dev(feat), _dev(cam), _dev(Rt)).cpu().numpy()
+    exp = oracle.triangulate(feat, cam, Rt)
+    assert np.array_equal(got, exp)      # same operation order, no FMA contraction on either side
+
+
+def test_full_frontend_pipeline_matches_oracle_chain(gpu, oracle):
+    """StereoOrbFrontend.process() end to end on 3 full-size frames == the oracle stage by stage."""
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    F, H, W = 3, 720, 1280
+    img = synth.stereo_frames(100, F)
+    fe = StereoOrbFrontend(H, W, max_frames=4, params=ImageProcessorParams())
+    res = fe.process(torch.from_numpy(img).cuda())
+    torch.cuda.synchronize()
+    p = fe.p
+    flat = img.reshape(2 * F, H, W)
+    kp, kc, blur, desc, ang = _pipeline_oracle(oracle, flat, p.max_features)
+    assert np.array_equal(res.kp_count.cpu().numpy(), kc)
+    assert np.array_equal(_u32(res.kp_keys), kp)                 # bit-exact FAST keypoint indices
+    assert np.array_equal(res.desc.cpu().numpy().view(np.uint64), desc)
+    f = np.arange(F, dtype=np.int32)
+    sidx, sdist = oracle.hamming_match(desc, kp, kc, W, 2 * f, 2 * f + 1, p.stereo_threshold,
+                                       p.min_disparity, p.max_disparity, p.stereo_max_distance)
+    tidx, tdist = oracle.hamming_match(desc, kp, kc, W, 2 * f[:-1], 2 * f[:-1] + 2, -1, 0, 0,
+                                       p.track_max_distance)
+    assert np.array_equal(res.stereo_idx.cpu().numpy(), sidx)    # bit-exact match pairs
+    assert np.array_equal(res.stereo_dist.cpu().numpy(), sdist)
+    assert np.array_equal(res.track_idx.cpu().numpy(), tidx)
+    assert np.array_equal(res.track_dist.cpu().numpy(), tdist)
+    # the emitted CameraMeasurement records carry the reference's field names and NDC convention
+    msgs = fe.camera_measurements(res)
+    assert len(msgs) == F and len(msgs[0].features) == int((sidx[0] >= 0).sum())
+    ft = msgs[1].features[0]
+    assert -1.0 <= ft.u0 <= 1.0 and -1.0 <= ft.v1 <= 1.0 and ft.id >= 0
+    ids0 = {f_.id for f_ in msgs[0].features}
+    assert len(ids0 & {f_.id for f_ in msgs[1].features}) > 50   # tracks persist across frames

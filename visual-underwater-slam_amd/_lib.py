@@ -1,0 +1,70 @@
+"""ctypes binding of libvus_hip.so (C ABI: include/vus.h).  Fails loudly when the library is absent."""
+import ctypes
+import os
+from ctypes import c_int, c_void_p, c_char_p, c_double
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libvus_hip.so")
+
+_P = c_void_p
+
+# name -> argtypes (all return int except where noted); mirrors include/vus.h line by line
+SIGNATURES = {
+    "vus_fast_score": [_P, c_int, c_int, c_int, c_int, c_int, _P, _P],
+    "vus_blur7": [_P, c_int, c_int, c_int, c_int, _P, _P],
+    "vus_fast_detect": [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
+    "vus_select_topk": [_P, _P, c_int, c_int, c_int, _P, _P, _P],
+    "vus_orient_rbrief": [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P],
+    "vus_hamming_match": [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
+    "vus_triangulate": [_P, c_int, _P, _P, _P, _P],
+}
+
+
+class VusError(RuntimeError):
+    """A libvus_hip.so entry point returned a negative code (gtsam raises RuntimeError likewise)."""
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C visual-underwater-slam_amd/csrc`. There is no CPU fallback.")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.vus_abi_version.restype = c_int
+    lib.vus_last_error.restype = c_char_p
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        raise VusError(f"{name} failed ({rc}): {lib.vus_last_error().decode()}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_ptr():
+    import torch
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_gpu():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("visual_underwater_slam_amd needs an MI355X (HIP device); no GPU is visible "
+                           "and there is deliberately no CPU fallback.")

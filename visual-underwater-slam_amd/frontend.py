@@ -1,0 +1,186 @@
+"""Host side of the stereo ORB front-end: the MI355X replacement of the reference's external
+image-processor nodelet.
+
+Interface mirrored: the nodelet is configured by the ROS parameters of
+/root/reference/launch/stereo.launch:37-47 (`fast_threshold`, `stereo_threshold`, ...) and publishes
+`gtsam_vio/CameraMeasurement` messages whose `features[].id, u0, v0, u1, v1` fields are what
+/root/reference/batch.py:149-154 reads.  `ImageProcessorParams` carries those parameter names,
+`StereoOrbFrontend.process()` runs the kernels on a whole resident batch of stereo frames, and
+`camera_measurements()` emits records of exactly that message shape.
+
+Python here only owns buffers and launches: every number is produced by libvus_hip.so.
+"""
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _lib
+
+
+@dataclass
+class ImageProcessorParams:
+    """Parameter names follow launch/stereo.launch:37-47 where the reference has one."""
+    fast_threshold: int = 10       # stereo.launch:43
+    stereo_threshold: int = 5      # stereo.launch:47 -- |v_left - v_right| gate in pixels
+    max_features: int = 2000       # BASELINE.json configs[1]: 2000 keypoints per image
+    border: int = 31               # ORB edge threshold (31x31 patch)
+    min_disparity: int = 0         # x_left - x_right gate of the stereo matcher
+    max_disparity: int = 128
+    stereo_max_distance: int = 64  # Hamming acceptance thresholds
+    track_max_distance: int = 64
+    cand_cap: int = 32768          # candidate slots per image before top-K selection
+
+
+@dataclass
+class Feature:
+    """One entry of CameraMeasurement.features (batch.py:149-154)."""
+    id: int
+    u0: float
+    v0: float
+    u1: float
+    v1: float
+
+
+@dataclass
+class CameraMeasurement:
+    features: List[Feature] = field(default_factory=list)
+
+
+class FrontendResult:
+    """Device tensors produced by one process() call (views into the front-end's workspace)."""
+
+    def __init__(self, fe, n_frames):
+        F = n_frames
+        self.n_frames = F
+        self.W = fe.W
+        self.H = fe.H
+        self.kp_keys = fe.kp_keys[:2 * F]
+        self.kp_count = fe.kp_count[:2 * F]
+        self.desc = fe.desc[:2 * F]
+        self.angle = fe.angle[:2 * F]
+        self.cand_count = fe.cand_count[:2 * F]
+        self.stereo_idx = fe.match_idx[:F]
+        self.stereo_dist = fe.match_dist[:F]
+        self.track_idx = fe.match_idx[fe.max_frames:fe.max_frames + max(F - 1, 0)]
+        self.track_dist = fe.match_dist[fe.max_frames:fe.max_frames + max(F - 1, 0)]
+
+    def keypoints_xy_score(self):
+        """Decode keys -> (x, y, score) int32 tensors [2F, K]; unused slots give score -1."""
+        k = self.kp_keys.to(torch.int64) & 0xFFFFFFFF
+        pos = k & 0xFFFFFF
+        score = 255 - (k >> 24)
+        valid = k != 0xFFFFFFFF
+        y = torch.div(pos, self.W, rounding_mode="floor")
+        x = pos - y * self.W
+        score = torch.where(valid, score, torch.full_like(score, -1))
+        return x.to(torch.int32), y.to(torch.int32), score.to(torch.int32)
+
+
+class StereoOrbFrontend:
+    """Batched stereo ORB: detect + describe both images of every frame, match left->right under
+    the epipolar gate and left(t)->left(t+1) for tracks.  All buffers are allocated once here."""
+
+    def __init__(self, H: int, W: int, max_frames: int, params: Optional[ImageProcessorParams] = None,
+                 device: str = "cuda:0"):
+        _lib.require_gpu()
+        _lib.load()
+        self.p = params or ImageProcessorParams()
+        self.H, self.W, self.max_frames = int(H), int(W), int(max_frames)
+        self.device = torch.device(device)
+        n_img, K, cap = 2 * self.max_frames, self.p.max_features, self.p.cand_cap
+        dev = self.device
+        self.blur = torch.empty((n_img, H, W), dtype=torch.uint8, device=dev)
+        self.cand_keys = torch.empty((n_img, cap), dtype=torch.int32, device=dev)
+        self.cand_count = torch.zeros((n_img,), dtype=torch.int32, device=dev)
+        self.kp_keys = torch.empty((n_img, K), dtype=torch.int32, device=dev)
+        self.kp_count = torch.zeros((n_img,), dtype=torch.int32, device=dev)
+        self.desc = torch.empty((n_img, K, 4), dtype=torch.int64, device=dev)
+        self.angle = torch.empty((n_img, K), dtype=torch.uint8, device=dev)
+        # rows [0, F): stereo pairs; rows [max_frames, max_frames + F - 1): temporal pairs
+        self.match_idx = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
+        self.match_dist = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
+        f = torch.arange(self.max_frames, dtype=torch.int32, device=dev)
+        self.stereo_q, self.stereo_t = (2 * f).contiguous(), (2 * f + 1).contiguous()
+        self.track_q, self.track_t = (2 * f).contiguous(), (2 * f + 2).contiguous()
+
+    def process(self, images: torch.Tensor, check: bool = True) -> FrontendResult:
+        """images: uint8 [F, 2, H, W] on the GPU (index 1: 0 = left / cam0, 1 = right / cam1).
+        Asynchronous on the current stream unless `check` (which reads the overflow counters)."""
+        assert images.dtype == torch.uint8 and images.is_cuda and images.is_contiguous()
+        F = images.shape[0]
+        assert images.shape[1:] == (2, self.H, self.W) and 1 <= F <= self.max_frames
+        p, H, W, K = self.p, self.H, self.W, self.p.max_features
+        n_img = 2 * F
+        st = _lib.current_stream_ptr()
+        ptr = _lib.ptr
+        self.cand_count[:n_img].zero_()
+        _lib.call("vus_fast_detect", ptr(images), n_img, H, W, W, p.fast_threshold, p.border,
+                  ptr(self.blur), ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
+        _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, K,
+                  ptr(self.kp_keys), ptr(self.kp_count), st)
+        _lib.call("vus_orient_rbrief", ptr(images), ptr(self.blur), n_img, H, W, W, ptr(self.kp_keys),
+                  ptr(self.kp_count), K, ptr(self.desc), ptr(self.angle), st)
+        _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, W,
+                  ptr(self.stereo_q), ptr(self.stereo_t), F, p.stereo_threshold, p.min_disparity,
+                  p.max_disparity, p.stereo_max_distance, ptr(self.match_idx), ptr(self.match_dist), st)
+        if F > 1:
+            _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, W,
+                      ptr(self.track_q), ptr(self.track_t), F - 1, -1, 0, 0, p.track_max_distance,
+                      ptr(self.match_idx[self.max_frames:]), ptr(self.match_dist[self.max_frames:]), st)
+        if check:
+            self.check_overflow(n_img)
+        return FrontendResult(self, F)
+
+    def check_overflow(self, n_img=None):
+        n_img = self.cand_count.shape[0] if n_img is None else n_img
+        worst = int(self.cand_count[:n_img].max().item())
+        if worst > self.p.cand_cap:
+            raise _lib.VusError(f"FAST produced {worst} candidates in one image, more than cand_cap="
+                                f"{self.p.cand_cap}: raise ImageProcessorParams.cand_cap")
+
+    # ------------------------------------------------------------------------------------------
+    def camera_measurements(self, res: FrontendResult) -> List[CameraMeasurement]:
+        """Per frame, the stereo-matched features as CameraMeasurement records with persistent ids
+        propagated along the left(t)->left(t+1) matches (normalised coordinates, so that
+        batch.py:152-154 maps them back to pixels of its 1920x1080 convention)."""
+        F, W, H = res.n_frames, self.W, self.H
+        x, y, _ = (t.cpu().numpy() for t in res.keypoints_xy_score())
+        sidx = res.stereo_idx.cpu().numpy()
+        tidx = res.track_idx.cpu().numpy() if F > 1 else None
+        cnt = res.kp_count.cpu().numpy()
+        out, next_id, prev_ids = [], 0, None
+        for f in range(F):
+            nl = int(cnt[2 * f])
+            ids = [-1] * nl
+            if prev_ids is not None:
+                for i_prev, j in enumerate(tidx[f - 1][:len(prev_ids)]):
+                    if j >= 0 and j < nl and prev_ids[i_prev] >= 0 and ids[j] < 0:
+                        ids[j] = prev_ids[i_prev]
+            msg = CameraMeasurement()
+            for i in range(nl):
+                j = int(sidx[f][i])
+                if j < 0:
+                    ids[i] = -1 if ids[i] < 0 else ids[i]
+                    continue
+                if ids[i] < 0:
+                    ids[i] = next_id
+                    next_id += 1
+                msg.features.append(Feature(
+                    id=ids[i],
+                    u0=2.0 * float(x[2 * f][i]) / W - 1.0, v0=2.0 * float(y[2 * f][i]) / H - 1.0,
+                    u1=2.0 * float(x[2 * f + 1][j]) / W - 1.0, v1=2.0 * float(y[2 * f + 1][j]) / H - 1.0))
+            out.append(msg)
+            prev_ids = ids
+        return out
+
+
+def triangulate(feat: torch.Tensor, cam: torch.Tensor, Rt: torch.Tensor) -> torch.Tensor:
+    """get_landmarks (batch.py:144-176) on the GPU: feat [n,4] f64 (u0,v0,u1,v1), cam [8] f64
+    (fx,fy,cx,cy,baseline,res_x,res_y,0), Rt [12] f64 -> [n,6] (X,Y,Z,uL,uR,v)."""
+    _lib.require_gpu()
+    assert feat.dtype == torch.float64 and feat.is_cuda and feat.is_contiguous() and feat.shape[1] == 4
+    out = torch.empty((feat.shape[0], 6), dtype=torch.float64, device=feat.device)
+    _lib.call("vus_triangulate", _lib.ptr(feat), feat.shape[0], _lib.ptr(cam), _lib.ptr(Rt), _lib.ptr(out),
+              _lib.current_stream_ptr())
+    return out

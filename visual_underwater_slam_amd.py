@@ -1,0 +1,12 @@
+"""Import alias: the package directory is named `visual-underwater-slam_amd/` (not a valid Python
+identifier), so this one-file module loads it as the package `visual_underwater_slam_amd`."""
+import importlib.util as _ilu
+import os as _os
+import sys as _sys
+
+_dir = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "visual-underwater-slam_amd")
+_spec = _ilu.spec_from_file_location(__name__, _os.path.join(_dir, "__init__.py"),
+                                     submodule_search_locations=[_dir])
+_mod = _ilu.module_from_spec(_spec)
+_sys.modules[__name__] = _mod
+_spec.loader.exec_module(_mod)
