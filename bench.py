@@ -1,0 +1,193 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the hot path on MI355X (contract in the task statement).
+
+Primary line (BASELINE.json configs[1]): ORB detect+match stereo frames/s on a synthetic
+1280x720 stereo stream, 2000 keypoints per image, 1000 frames resident in HBM per GPU.
+One "step" = one pass of the whole front-end (FAST+NMS+smoothing, top-2000 selection, orientation
++ rBRIEF, left->right and left(t)->left(t+1) brute-force Hamming) over the rank's 1000-frame shard.
+With N ranks every rank owns its own 1000-frame shard (frames are independent: no data-path
+collective), so the job is N*1000 frames per step: "scaling": "weak".
+
+The same JSON line carries `roofline` (dominant kernel, HIP-event timed inside the timed region),
+`cpu_baseline` (the C oracle on a bounded sample of the same stream, on this host's cores) and,
+once the BA kernels exist, `ba` (full-batch LM wall time at 2000 keyframes / 50k landmarks).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+H, W, KP = 720, 1280, 2000
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+# Algorithmic bytes (single pyramid level), per stereo frame:
+#   fast_detect : 2 images read once (2*H*W) + 2*2000 keypoint records of 16 B
+#   select_topk : candidates read once is an implementation artefact -> counted as keypoint records above
+#   orient_rbrief: 2*2000 descriptors of 32 B written
+#   hamming     : descriptors re-read once (2*2000*32) + 2000 matches * 8 B
+ALGO_BYTES = {
+    "fast_detect": 2 * H * W + 2 * KP * 16,
+    "select_topk": 2 * KP * 4,
+    "orient_rbrief": 2 * KP * 32,
+    "hamming_stereo": 2 * KP * 32 + KP * 8,
+    "hamming_track": 2 * KP * 32 + KP * 8,
+}
+ALGO_BYTES_FRAME = 2 * H * W + 2 * KP * 16 + 2 * KP * 32 + 2 * KP * 32 + KP * 8  # = 2,179,200
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=1000, help="frames per GPU (configs[1]: 1000)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="bounded cpu_baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    return ap.parse_args()
+
+
+def make_stream(n_frames, t0, device):
+    from visual_underwater_slam_amd import synth
+    cv = synth.canvas(torch, device)
+    out = torch.empty((n_frames, 2, H, W), dtype=torch.uint8, device=device)
+    chunk = 8
+    for s in range(0, n_frames, chunk):
+        n = min(chunk, n_frames - s)
+        out[s:s + n] = synth.stereo_frames(t0 + s, n, H, W, xp=torch, device=device, canvas_arr=cv)
+    return out
+
+
+def timed_stage_process(fe, images, events):
+    """fe.process() with a HIP event recorded (on the launch stream) around every kernel."""
+    from visual_underwater_slam_amd import _lib
+    p, F, K = fe.p, images.shape[0], fe.p.max_features
+    n_img = 2 * F
+    st = _lib.current_stream_ptr()
+    ptr = _lib.ptr
+    fe.cand_count[:n_img].zero_()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
+    ev[0].record()
+    _lib.call("vus_fast_detect", ptr(images), n_img, H, W, W, p.fast_threshold, p.border, ptr(fe.blur),
+              ptr(fe.cand_keys), p.cand_cap, ptr(fe.cand_count), st)
+    ev[1].record()
+    _lib.call("vus_select_topk", ptr(fe.cand_keys), ptr(fe.cand_count), n_img, p.cand_cap, K,
+              ptr(fe.kp_keys), ptr(fe.kp_count), st)
+    ev[2].record()
+    _lib.call("vus_orient_rbrief", ptr(images), ptr(fe.blur), n_img, H, W, W, ptr(fe.kp_keys),
+              ptr(fe.kp_count), K, ptr(fe.desc), ptr(fe.angle), st)
+    ev[3].record()
+    _lib.call("vus_hamming_match", ptr(fe.desc), ptr(fe.kp_keys), ptr(fe.kp_count), K, W, ptr(fe.stereo_q),
+              ptr(fe.stereo_t), F, p.stereo_threshold, p.min_disparity, p.max_disparity,
+              p.stereo_max_distance, ptr(fe.match_idx), ptr(fe.match_dist), st)
+    ev[4].record()
+    _lib.call("vus_hamming_match", ptr(fe.desc), ptr(fe.kp_keys), ptr(fe.kp_count), K, W, ptr(fe.track_q),
+              ptr(fe.track_t), F - 1, -1, 0, 0, p.track_max_distance, ptr(fe.match_idx[fe.max_frames:]),
+              ptr(fe.match_dist[fe.max_frames:]), st)
+    ev[5].record()
+    events.append(ev)
+
+
+def cpu_baseline(n_frames, t0):
+    """The C oracle ("port") on the first n_frames of the same stream, all host cores."""
+    import numpy as np
+    from visual_underwater_slam_amd import synth
+    from oracle import oracle as O
+    cores = os.cpu_count() or 1
+    O.lib().vus_oracle_set_threads(cores)
+    img = synth.stereo_frames(t0, n_frames).reshape(2 * n_frames, H, W)
+    t = time.perf_counter()
+    keys, cnt, blur = O.fast_detect(img)
+    kp, kc = O.select_topk(keys, cnt, KP)
+    desc, _ = O.orient_rbrief(img, blur, kp, kc)
+    f = np.arange(n_frames, dtype=np.int32)
+    O.hamming_match(desc, kp, kc, W, 2 * f, 2 * f + 1, 5, 0, 128, 64)
+    O.hamming_match(desc, kp, kc, W, 2 * f[:-1], 2 * f[:-1] + 2, -1, 0, 0, 64)
+    dt = time.perf_counter() - t
+    return {"value": round(n_frames / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": f"first {n_frames} stereo frames of the same synthetic stream, C oracle "
+                      f"(gcc -O2, OpenMP over images), {dt:.2f} s"}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    F = a.frames
+    images = make_stream(F, rank * F, device)        # this rank's shard of the stream, resident in HBM
+    fe = StereoOrbFrontend(H, W, max_frames=F, params=ImageProcessorParams(max_features=KP), device=device)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        fe.process(images, check=False)
+    barrier()
+    fe.check_overflow()
+    events = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        timed_stage_process(fe, images, events)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    names = ["fast_detect", "select_topk", "orient_rbrief", "hamming_stereo", "hamming_track"]
+    stage_ms = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in events) / len(events) for i, n in enumerate(names)}
+    dom = max(stage_ms, key=stage_ms.get)
+    achieved = ALGO_BYTES[dom] * F / (stage_ms[dom] * 1e-3) / 1e9
+    out = {
+        "metric": "ORB detect+match frames/sec", "value": round(world * F * a.steps / dt, 2),
+        "unit": "stereo frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": round(dt / a.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+        "config": {"workload": "configs[1]: stereo ORB detect+match, 1280x720, 2000 kpts/image, "
+                               f"{F}-frame stream per GPU resident in HBM, single pyramid level",
+                   "frames_per_gpu": F, "keypoints_per_image": KP, "fast_threshold": 10,
+                   "parallelism": f"frames sharded x{world}, no data-path collective"},
+        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        "pipeline_GBps": round(ALGO_BYTES_FRAME * F * a.steps / dt / 1e9 * world, 2),
+        "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
+    }
+    if rank == 0:
+        if not a.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(a.cpu_frames, 0)
+        if not a.no_ba:
+            try:
+                from visual_underwater_slam_amd import ba_bench
+                out["ba"] = ba_bench.run(device)
+            except ImportError:
+                pass
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -23,8 +23,20 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "../include/vus.h"
 #include "../include/vus_orb_tables.h"
+
+/* Thread count of the image/pair-level OpenMP loops (the cpu_baseline leg states it as `cores`). */
+void vus_oracle_set_threads(int n) {
+#ifdef _OPENMP
+  omp_set_num_threads(n < 1 ? 1 : n);
+#else
+  (void)n;
+#endif
+}
 
 static inline int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -69,9 +81,9 @@ int vus_fast_score_cpu(const uint8_t* img, int n_img, int H, int W, int pitch, i
 
 int vus_blur7_cpu(const uint8_t* img, int n_img, int H, int W, int pitch, uint8_t* out) {
   if (!img || !out || n_img < 0 || H < 1 || W < 1 || pitch < W) return VUS_E_INVALID;
-  int32_t* tmp = (int32_t*)malloc((size_t)H * W * sizeof(int32_t));
-  if (!tmp) return VUS_E_INVALID;
+#pragma omp parallel for schedule(dynamic)
   for (int n = 0; n < n_img; ++n) {
+    int32_t* tmp = (int32_t*)malloc((size_t)H * W * sizeof(int32_t));
     const uint8_t* im = img + (size_t)n * H * pitch;
     uint8_t* o = out + (size_t)n * H * W;
     for (int y = 0; y < H; ++y)
@@ -86,8 +98,8 @@ int vus_blur7_cpu(const uint8_t* img, int n_img, int H, int W, int pitch, uint8_
         for (int k = 0; k < 7; ++k) acc += VUS_BLUR_W[k] * tmp[clampi(y + k - 3, 0, H - 1) * W + x];
         o[y * W + x] = (uint8_t)((acc + 32768) >> 16);
       }
+    free(tmp);
   }
-  free(tmp);
   return VUS_OK;
 }
 
@@ -97,11 +109,11 @@ int vus_fast_detect_cpu(const uint8_t* img, int n_img, int H, int W, int pitch, 
                         uint8_t* blur_out, uint32_t* cand_keys, int cand_cap, int* cand_count) {
   if (!img || !cand_keys || !cand_count || cand_cap < 1 || border < 0) return VUS_E_INVALID;
   if ((long long)H * W > (1ll << VUS_KEY_POS_BITS)) return VUS_E_INVALID;
-  uint8_t* sc = (uint8_t*)malloc((size_t)H * W);
-  if (!sc) return VUS_E_INVALID;
+  if (thr < 1 || thr > 254 || H < 7 || W < 7 || pitch < W) return VUS_E_INVALID;
+#pragma omp parallel for schedule(dynamic)
   for (int n = 0; n < n_img; ++n) {
-    int rc = vus_fast_score_cpu(img + (size_t)n * H * pitch, 1, H, W, pitch, thr, sc);
-    if (rc) { free(sc); return rc; }
+    uint8_t* sc = (uint8_t*)malloc((size_t)H * W);
+    vus_fast_score_cpu(img + (size_t)n * H * pitch, 1, H, W, pitch, thr, sc);
     int cnt = 0;
     uint32_t* keys = cand_keys + (size_t)n * cand_cap;
     for (int y = border; y < H - border; ++y)
@@ -121,8 +133,8 @@ int vus_fast_detect_cpu(const uint8_t* img, int n_img, int H, int W, int pitch, 
         ++cnt;
       }
     cand_count[n] = cnt;
+    free(sc);
   }
-  free(sc);
   if (blur_out) return vus_blur7_cpu(img, n_img, H, W, pitch, blur_out);
   return VUS_OK;
 }
@@ -155,6 +167,7 @@ int vus_orient_rbrief_cpu(const uint8_t* img, const uint8_t* blur, int n_img, in
                           const uint32_t* kp_keys, const int* kp_count, int max_kp,
                           uint64_t* desc_out, uint8_t* angle_out) {
   if (!img || !blur || !kp_keys || !kp_count || !desc_out || !angle_out) return VUS_E_INVALID;
+#pragma omp parallel for schedule(dynamic)
   for (int n = 0; n < n_img; ++n) {
     const uint8_t* im = img + (size_t)n * H * pitch;
     const uint8_t* bl = blur + (size_t)n * H * W;
@@ -197,6 +210,7 @@ int vus_hamming_match_cpu(const uint64_t* desc, const uint32_t* kp_keys, const i
                           int32_t* idx_out, int32_t* dist_out) {
   if (!desc || !kp_keys || !kp_count || !q_index || !t_index || !idx_out || !dist_out || W < 1)
     return VUS_E_INVALID;
+#pragma omp parallel for schedule(dynamic)
   for (int p = 0; p < n_pairs; ++p) {
     int qi = q_index[p], ti = t_index[p];
     const uint64_t* dq = desc + (size_t)qi * max_kp * 4;

@@ -9,11 +9,17 @@ from visual_underwater_slam_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _dev(a, dtype=None):
-    t = torch.from_numpy(np.ascontiguousarray(a))
-    if dtype is not None:
-        t = t.view(dtype) if t.element_size() == torch.empty((), dtype=dtype).element_size() else t.to(dtype)
-    return t.cuda()
+_KEEP = []   # device inputs stay referenced until the test module is done: a freed tensor's memory
+             # would be handed to the next allocation while a launched kernel still reads it
+
+
+def _dev(a):
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    _KEEP.append(t)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return t
 
 
 def _u32(t):

@@ -31,6 +31,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch bundles its own libamdhip64.so (soname libamdhip64.so.7).  Import it FIRST so that this
+    # library binds to the same HIP runtime instance; loaded the other way round the process ends
+    # up with two runtimes and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
