@@ -96,6 +96,90 @@ int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, const int* 
 int vus_triangulate(const double* feat, int n, const double* cam, const double* Rt, double* out,
                     void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Stereo bundle adjustment: what gtsam.LevenbergMarquardtOptimizer(graph, values, params)
+ * .optimize() (batch.py:337) spends its time on, for a graph of GenericStereoFactor3D factors
+ * (batch.py:300-305) plus PriorFactorPose3 gauge priors (batch.py:281).  All fp64.
+ *
+ * Variables: poses [n_poses,12] = row-major 3x3 R then t (camera-to-world, gtsam.Pose3);
+ *            points [n_points,3].
+ * Pose tangent: xi = (omega, v), right perturbation T * Exp(xi)  (gtsam Pose3 convention).
+ * Observations are stored twice-indexed:
+ *   "L-order": sorted by (point, pose); point_ptr is the CSR row pointer over it;
+ *   "P-order": sorted by (pose, point); pose_ptr is the CSR row pointer over it.
+ * Per-observation Jacobian products W, Y live in P-order.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct vus_ba_problem {
+  int n_poses, n_points, n_obs, n_priors;
+  const double* K;         /* [6] fx, fy, skew (ignored, as gtsam's StereoCamera does), cx, cy, baseline */
+  double inv_sigma;        /* 1/sigma of the isotropic stereo noise model (batch.py:118: sigma = 10) */
+  const double* meas;      /* [n_obs,3] (uL, uR, v), L-order */
+  const int* obs_pose;     /* [n_obs] L-order */
+  const int* obs_point;    /* [n_obs] L-order */
+  const int* point_ptr;    /* [n_points+1] */
+  const int* obs_ppos;     /* [n_obs] L-order index -> P-order slot */
+  const int* pose_ptr;     /* [n_poses+1] */
+  const int* pobs_lidx;    /* [n_obs] P-order slot -> L-order index */
+  const int* prior_pose;   /* [n_priors] pose index of each PriorFactorPose3 */
+  const double* prior_T;   /* [n_priors,12] prior mean */
+  const double* prior_w;   /* [n_priors,6] 1/sigma per tangent coordinate (rot xyz, trans xyz) */
+} vus_ba_problem;
+
+/* Block structure of the reduced camera system S (built once per graph by the host):
+ * lower block band of half-width `band` pose blocks; non-zero block (blk_i >= blk_k) number q owns
+ * pairs [blk_ptr[q], blk_ptr[q+1]) of P-order slots (pair_a: the observation of pose blk_i,
+ * pair_b: of pose blk_k) that see the same point.  S band storage: [n_poses, band+1, 6, 6],
+ * entry (i, s) = block (i, i - s). */
+typedef struct vus_ba_structure {
+  int band;
+  int n_blocks;
+  int n_pairs;
+  const int* blk_ptr;      /* [n_blocks+1] */
+  const int* blk_i;        /* [n_blocks] */
+  const int* blk_k;        /* [n_blocks] */
+  const int* pair_a;       /* [n_pairs] */
+  const int* pair_b;       /* [n_pairs] */
+} vus_ba_structure;
+
+/* Linearise every factor at (poses, points):
+ *   W   [n_obs,18]  H1^T H2 (6x3 row-major) per observation, P-order, whitened
+ *   V   [n_points,6] sum H2^T H2, upper triangle (xx,xy,xz,yy,yz,zz)
+ *   gl  [n_points,3] sum H2^T r
+ *   Hpp [n_poses,36] sum H1^T H1 + prior information;  gp [n_poses,6] sum H1^T r + prior part
+ *   err [1]          0.5 * sum |whitened residual|^2 over stereo factors and priors
+ * Stereo residual/Jacobians follow gtsam::GenericStereoFactor / StereoCamera::project2
+ * (cheirality z <= 0: residual 2*fx on all three rows, zero Jacobians). */
+int vus_ba_linearize(const vus_ba_problem* P, const double* poses, const double* points,
+                     double* W, double* V, double* gl, double* Hpp, double* gp, double* err,
+                     void* stream);
+
+/* Damped landmark elimination for one lambda (lambda*I damping, gtsam diagonalDamping=false):
+ *   Vinv [n_points,6] = (V + lambda I)^-1 (upper triangle);  Y [n_obs,18] = W Vinv (P-order);
+ *   S band (see vus_ba_structure) = Hpp + lambda I - sum_j Y W^T;  gs [n_poses,6] = gp - sum Y gl. */
+int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lambda,
+                 const double* W, const double* V, const double* gl, const double* Hpp,
+                 const double* gp, double* Vinv, double* Y, double* Sband, double* gs, void* stream);
+
+/* Solve S dp = -gs by block-band Cholesky (Sband is overwritten by its factor).
+ * status[0] = 0 ok, k+1 = non-positive pivot met in scalar column k (dp is then undefined). */
+int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, double* dp,
+                      int* status, void* stream);
+
+/* dl [n_points,3] = -Vinv (gl + sum_a W_a^T dp[pose_a]). */
+int vus_ba_backsub(const vus_ba_problem* P, const double* W, const double* Vinv, const double* gl,
+                   const double* dp, double* dl, void* stream);
+
+/* Evaluate a step: new_poses = poses (+) dp (Pose3 retract = T * Expmap(xi)), new_points = points + dl,
+ * out[0] = linearised error at the step 0.5*sum|r + J d|^2 (J at the OLD values, undamped),
+ * out[1] = nonlinear error at the new values (stereo factors + priors). */
+int vus_ba_eval_step(const vus_ba_problem* P, const double* poses, const double* points,
+                     const double* dp, const double* dl, double* new_poses, double* new_points,
+                     double* out, void* stream);
+
+/* err[0] = 0.5 * sum |whitened residual|^2 at (poses, points): NonlinearFactorGraph.error(). */
+int vus_ba_error(const vus_ba_problem* P, const double* poses, const double* points, double* err,
+                 void* stream);
+
 #ifdef __cplusplus
 }
 #endif

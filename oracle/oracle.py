@@ -118,3 +118,147 @@ def triangulate(feat, cam, Rt):
     out = np.empty((n, 6), np.float64)
     _check(lib().vus_triangulate_cpu(_p(feat), n, _p(cam), _p(Rt), _p(out)), "triangulate")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# bundle adjustment (oracle/vus_oracle_ba.c)
+class _BAProblem(ctypes.Structure):
+    _fields_ = [("n_poses", c_int), ("n_points", c_int), ("n_obs", c_int), ("n_priors", c_int),
+                ("K", c_void_p), ("inv_sigma", c_double), ("meas", c_void_p), ("obs_pose", c_void_p),
+                ("obs_point", c_void_p), ("point_ptr", c_void_p), ("obs_ppos", c_void_p),
+                ("pose_ptr", c_void_p), ("pobs_lidx", c_void_p), ("prior_pose", c_void_p),
+                ("prior_T", c_void_p), ("prior_w", c_void_p)]
+
+
+class _BAStructure(ctypes.Structure):
+    _fields_ = [("band", c_int), ("n_blocks", c_int), ("n_pairs", c_int), ("blk_ptr", c_void_p),
+                ("blk_i", c_void_p), ("blk_k", c_void_p), ("pair_a", c_void_p), ("pair_b", c_void_p)]
+
+
+class _LMParams(ctypes.Structure):
+    _fields_ = [("lambda_initial", c_double), ("lambda_factor", c_double), ("lambda_upper", c_double),
+                ("lambda_lower", c_double), ("min_model_fidelity", c_double), ("rel_tol", c_double),
+                ("abs_tol", c_double), ("error_tol", c_double), ("max_iterations", c_int)]
+
+
+class _LMReport(ctypes.Structure):
+    _fields_ = [("iterations", c_int), ("outer", c_int), ("tries", c_int), ("status", c_int),
+                ("initial_error", c_double), ("final_error", c_double), ("final_lambda", c_double),
+                ("err_hist", c_double * 128), ("lambda_hist", c_double * 128)]
+
+
+class BAProblem:
+    """Host-side (numpy) vus_ba_problem.  `pk` is the dict of ba_pack.pack_observations (numpy or
+    CPU torch tensors), priors = (pose_idx [n], T [n,12], sigmas [n,6])."""
+
+    def __init__(self, pk, K, sigma, priors=None):
+        def np_(x, dt):
+            x = x.numpy() if hasattr(x, "numpy") else x
+            return np.ascontiguousarray(x, dtype=dt)
+        self.n_poses, self.n_points, self.n_obs = pk["n_poses"], pk["n_points"], pk["n_obs"]
+        self.K = np_(K, np.float64)
+        self.meas = np_(pk["meas"], np.float64)
+        self.arr = {k: np_(pk[k], np.int32) for k in
+                    ("obs_pose", "obs_point", "point_ptr", "obs_ppos", "pose_ptr", "pobs_lidx")}
+        if priors is None:
+            priors = (np.zeros(0, np.int32), np.zeros((0, 12)), np.zeros((0, 6)))
+        self.prior_pose = np_(priors[0], np.int32)
+        self.prior_T = np_(priors[1], np.float64)
+        self.prior_w = np.ascontiguousarray(1.0 / np_(priors[2], np.float64)) if len(priors[0]) else np.zeros((0, 6))
+        self.c = _BAProblem(self.n_poses, self.n_points, self.n_obs, len(self.prior_pose), _p(self.K).value,
+                            1.0 / float(sigma), _p(self.meas).value, _p(self.arr["obs_pose"]).value,
+                            _p(self.arr["obs_point"]).value, _p(self.arr["point_ptr"]).value,
+                            _p(self.arr["obs_ppos"]).value, _p(self.arr["pose_ptr"]).value,
+                            _p(self.arr["pobs_lidx"]).value, _p(self.prior_pose).value if len(self.prior_pose) else None,
+                            _p(self.prior_T).value if len(self.prior_pose) else None,
+                            _p(self.prior_w).value if len(self.prior_pose) else None)
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+
+def _f64(a):
+    return np.ascontiguousarray(a, dtype=np.float64)
+
+
+def ba_error(P, poses, points):
+    e = np.zeros(1)
+    _check(lib().vus_ba_error_cpu(P.ref(), _p(_f64(poses)), _p(_f64(points)), _p(e)), "ba_error")
+    return float(e[0])
+
+
+def ba_linearize(P, poses, points):
+    W = np.zeros((P.n_obs, 18)); V = np.zeros((P.n_points, 6)); gl = np.zeros((P.n_points, 3))
+    Hpp = np.zeros((P.n_poses, 36)); gp = np.zeros((P.n_poses, 6)); e = np.zeros(1)
+    _check(lib().vus_ba_linearize_cpu(P.ref(), _p(_f64(poses)), _p(_f64(points)), _p(W), _p(V), _p(gl),
+                                      _p(Hpp), _p(gp), _p(e)), "ba_linearize")
+    return {"W": W, "V": V, "gl": gl, "Hpp": Hpp, "gp": gp, "err": float(e[0])}
+
+
+def ba_schur(P, band, lam, lin):
+    S = _BAStructure(int(band), 0, 0, None, None, None, None, None)
+    Vinv = np.zeros((P.n_points, 6)); Y = np.zeros((P.n_obs, 18))
+    Sb = np.zeros((P.n_poses, band + 1, 36)); gs = np.zeros((P.n_poses, 6))
+    _check(lib().vus_ba_schur_cpu(P.ref(), ctypes.byref(S), c_double(lam), _p(lin["W"]), _p(lin["V"]),
+                                  _p(lin["gl"]), _p(lin["Hpp"]), _p(lin["gp"]), _p(Vinv), _p(Y), _p(Sb), _p(gs)),
+           "ba_schur")
+    return {"Vinv": Vinv, "Y": Y, "Sband": Sb, "gs": gs}
+
+
+def ba_band_solve(Sband, gs):
+    Sb = np.array(Sband, dtype=np.float64, order="C", copy=True)
+    nP, B1 = Sb.shape[0], Sb.shape[1]
+    dp = np.zeros((nP, 6)); st = np.zeros(1, np.int32)
+    _check(lib().vus_ba_band_solve_cpu(_p(Sb), nP, B1 - 1, _p(_f64(gs)), _p(dp), _p(st)), "ba_band_solve")
+    return dp, int(st[0]), Sb
+
+
+def ba_backsub(P, lin, Vinv, dp):
+    dl = np.zeros((P.n_points, 3))
+    _check(lib().vus_ba_backsub_cpu(P.ref(), _p(lin["W"]), _p(_f64(Vinv)), _p(lin["gl"]), _p(_f64(dp)), _p(dl)),
+           "ba_backsub")
+    return dl
+
+
+def ba_eval_step(P, poses, points, dp, dl):
+    npo = np.zeros((P.n_poses, 12)); npt = np.zeros((P.n_points, 3)); out = np.zeros(2)
+    _check(lib().vus_ba_eval_step_cpu(P.ref(), _p(_f64(poses)), _p(_f64(points)), _p(_f64(dp)), _p(_f64(dl)),
+                                      _p(npo), _p(npt), _p(out)), "ba_eval_step")
+    return npo, npt, float(out[0]), float(out[1])
+
+
+LM_DEFAULTS = dict(lambda_initial=1e-5, lambda_factor=10.0, lambda_upper=1e5, lambda_lower=0.0,
+                   min_model_fidelity=1e-3, rel_tol=1e-5, abs_tol=1e-5, error_tol=0.0, max_iterations=100)
+
+
+def ba_lm_optimize(P, band, poses, points, **params):
+    prm = dict(LM_DEFAULTS); prm.update(params)
+    c = _LMParams(*[prm[k] for k, _ in _LMParams._fields_])
+    rep = _LMReport()
+    poses = np.array(poses, dtype=np.float64, order="C", copy=True)
+    points = np.array(points, dtype=np.float64, order="C", copy=True)
+    _check(lib().vus_ba_lm_optimize_cpu(P.ref(), int(band), ctypes.byref(c), _p(poses), _p(points),
+                                        ctypes.byref(rep)), "ba_lm_optimize")
+    n = min(rep.outer, 128)
+    return poses, points, {"iterations": rep.iterations, "outer": rep.outer, "tries": rep.tries,
+                           "status": rep.status, "initial_error": rep.initial_error,
+                           "final_error": rep.final_error, "final_lambda": rep.final_lambda,
+                           "err_hist": list(rep.err_hist[:n]), "lambda_hist": list(rep.lambda_hist[:n])}
+
+
+def stereo_factor(T, p, m, K, w):
+    r = np.zeros(3); H1 = np.zeros(18); H2 = np.zeros(9)
+    lib().vus_stereo_factor_cpu(_p(_f64(T)), _p(_f64(p)), _p(_f64(m)), _p(_f64(K)), c_double(w), _p(r), _p(H1), _p(H2))
+    return r, H1.reshape(3, 6), H2.reshape(3, 3)
+
+
+def pose_retract(T, xi):
+    out = np.zeros(12)
+    lib().vus_pose_retract_cpu(_p(_f64(T)), _p(_f64(xi)), _p(out))
+    return out
+
+
+def pose_local(T, T2):
+    xi = np.zeros(6)
+    lib().vus_pose_local_cpu(_p(_f64(T)), _p(_f64(T2)), _p(xi))
+    return xi

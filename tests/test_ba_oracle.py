@@ -1,0 +1,217 @@
+"""Pins the CPU oracle of the BA path: finite-difference Jacobians, Lie-group
+identities, Schur+band solve == dense solve, LM recovers ground truth.  The reference has no golden
+vectors for this path (GTSAM is un-vendored: parity unpinned), so these are first-principles checks."""
+import numpy as np
+import pytest
+import torch
+
+from visual_underwater_slam_amd import synth, ba_pack
+
+K = np.array([1827.0, 1827.5999755859375, 0.0, 968.9000244140625, 561.4000244140625, 0.063])
+
+
+def rand_pose(rng):
+    A = rng.normal(size=(3, 3))
+    Q, _ = np.linalg.qr(A)
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] *= -1
+    return np.concatenate([Q.reshape(-1), rng.normal(size=3)])
+
+
+def test_retract_local_are_inverse_and_match_scipy(oracle):
+    from scipy.linalg import expm, logm
+    rng = np.random.default_rng(0)
+    for scale in (1e-9, 1e-3, 0.3, 3.0):
+        T = rand_pose(rng)
+        xi = rng.normal(size=6) * scale
+        xi[:3] *= scale / np.linalg.norm(xi[:3])     # rotation angle = scale (< pi: Logmap is the inverse)
+        T2 = oracle.pose_retract(T, xi)
+        assert np.allclose(oracle.pose_local(T, T2), xi, rtol=1e-9, atol=1e-12)
+        # SE(3) exponential as a 4x4 matrix exponential
+        X = np.zeros((4, 4))
+        X[:3, :3] = [[0, -xi[2], xi[1]], [xi[2], 0, -xi[0]], [-xi[1], xi[0], 0]]
+        X[:3, 3] = xi[3:]
+        M = np.eye(4); M[:3, :3] = T[:9].reshape(3, 3); M[:3, 3] = T[9:]
+        M2 = M @ expm(X)
+        assert np.allclose(T2[:9].reshape(3, 3), M2[:3, :3], atol=1e-12)
+        assert np.allclose(T2[9:], M2[:3, 3], atol=1e-12)
+        R2 = T2[:9].reshape(3, 3)
+        assert np.allclose(R2 @ R2.T, np.eye(3), atol=1e-13)
+
+
+def test_stereo_projection_values(oracle):
+    """Identity pose, a point on the optical axis 2 m ahead: uL = cx, uR = cx - fx*b/z, v = cy."""
+    T = np.concatenate([np.eye(3).reshape(-1), np.zeros(3)])
+    r, H1, H2 = oracle.stereo_factor(T, [0, 0, 2.0], [0, 0, 0], K, 1.0)
+    assert np.allclose(r, [K[3], K[3] - K[0] * K[5] / 2.0, K[4]], rtol=1e-15)
+    # whitening scales residual and Jacobians alike
+    r2, H1b, H2b = oracle.stereo_factor(T, [0, 0, 2.0], [0, 0, 0], K, 0.1)
+    assert np.allclose(r2, 0.1 * r) and np.allclose(H1b, 0.1 * H1) and np.allclose(H2b, 0.1 * H2)
+
+
+def test_stereo_jacobians_match_central_differences(oracle):
+    rng = np.random.default_rng(1)
+    for _ in range(20):
+        T = rand_pose(rng)
+        R = T[:9].reshape(3, 3)
+        q = np.array([rng.uniform(-1, 1), rng.uniform(-0.6, 0.6), rng.uniform(1.5, 6)])
+        p = R @ q + T[9:]
+        m = rng.uniform(0, 1000, 3)
+        w = 0.1
+        r, H1, H2 = oracle.stereo_factor(T, p, m, K, w)
+        h = 1e-6
+        H1n = np.zeros((3, 6)); H2n = np.zeros((3, 3))
+        for k in range(6):
+            e = np.zeros(6); e[k] = h
+            rp, _, _ = oracle.stereo_factor(oracle.pose_retract(T, e), p, m, K, w)
+            rm, _, _ = oracle.stereo_factor(oracle.pose_retract(T, -e), p, m, K, w)
+            H1n[:, k] = (rp - rm) / (2 * h)
+        for k in range(3):
+            e = np.zeros(3); e[k] = h
+            rp, _, _ = oracle.stereo_factor(T, p + e, m, K, w)
+            rm, _, _ = oracle.stereo_factor(T, p - e, m, K, w)
+            H2n[:, k] = (rp - rm) / (2 * h)
+        assert np.allclose(H1, H1n, rtol=1e-6, atol=1e-6 * np.abs(H1).max())
+        assert np.allclose(H2, H2n, rtol=1e-6, atol=1e-6 * np.abs(H2).max())
+
+
+def test_cheirality_gives_constant_residual_and_zero_jacobians(oracle):
+    T = np.concatenate([np.eye(3).reshape(-1), np.zeros(3)])
+    r, H1, H2 = oracle.stereo_factor(T, [0.1, 0.2, -1.0], [5, 6, 7], K, 0.1)
+    assert np.allclose(r, 2 * K[0] * 0.1) and not H1.any() and not H2.any()
+    r, H1, H2 = oracle.stereo_factor(T, [0.1, 0.2, 0.0], [5, 6, 7], K, 0.1)
+    assert np.allclose(r, 2 * K[0] * 0.1)
+
+
+def small_problem(oracle, n_kf=12, n_lm=60, obs=30, seed_shift=0):
+    s = synth.ba_sequence(n_kf, n_lm, obs, seed=synth.SEED + seed_shift)
+    nL = len(s["points_gt"])
+    pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"]), torch.from_numpy(s["obs_point"]),
+                                   torch.from_numpy(s["meas"]), n_kf, nL)
+    st = ba_pack.build_structure(pk)
+    pri = (np.array([0], np.int32), s["poses_gt"][:1], s["prior_sigmas"][None])
+    return s, pk, st, oracle.BAProblem(pk, s["K"], s["sigma"], pri)
+
+
+def dense_system(oracle, P, s, pk, poses, points):
+    """Assemble the full (6 nP + 3 nL) Jacobian from per-factor blocks and return J, r."""
+    nP, nL, nO = P.n_poses, P.n_points, P.n_obs
+    J = np.zeros((3 * nO + 6, 6 * nP + 3 * nL)); r = np.zeros(3 * nO + 6)
+    op, ol, meas = pk["obs_pose"].numpy(), pk["obs_point"].numpy(), pk["meas"].numpy()
+    for a in range(nO):
+        ra, H1, H2 = oracle.stereo_factor(poses[op[a]], points[ol[a]], meas[a], s["K"], 1.0 / s["sigma"])
+        J[3 * a:3 * a + 3, 6 * op[a]:6 * op[a] + 6] = H1
+        J[3 * a:3 * a + 3, 6 * nP + 3 * ol[a]:6 * nP + 3 * ol[a] + 3] = H2
+        r[3 * a:3 * a + 3] = ra
+    w = 1.0 / s["prior_sigmas"]
+    J[3 * nO:, 0:6] = np.diag(w)
+    r[3 * nO:] = -oracle.pose_local(poses[0], s["poses_gt"][0]) * w
+    return J, r
+
+
+def test_linearize_matches_dense_normal_equations(oracle):
+    s, pk, st, P = small_problem(oracle)
+    poses, points = s["poses_init"], s["points_init"]
+    lin = oracle.ba_linearize(P, poses, points)
+    J, r = dense_system(oracle, P, s, pk, poses, points)
+    H = J.T @ J; g = J.T @ r
+    nP, nL = P.n_poses, P.n_points
+    assert np.isclose(lin["err"], 0.5 * r @ r, rtol=1e-13)
+    assert np.isclose(lin["err"], oracle.ba_error(P, poses, points), rtol=1e-14)
+    for i in range(nP):
+        assert np.allclose(lin["Hpp"][i].reshape(6, 6), H[6 * i:6 * i + 6, 6 * i:6 * i + 6], rtol=1e-11, atol=1e-9)
+    assert np.allclose(lin["gp"].reshape(-1), g[:6 * nP], rtol=1e-11, atol=1e-9)
+    assert np.allclose(lin["gl"].reshape(-1), g[6 * nP:], rtol=1e-11, atol=1e-9)
+    iu = [(0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2)]
+    for j in range(nL):
+        Vj = H[6 * nP + 3 * j:6 * nP + 3 * j + 3, 6 * nP + 3 * j:6 * nP + 3 * j + 3]
+        assert np.allclose(lin["V"][j], [Vj[a, b] for a, b in iu], rtol=1e-11, atol=1e-9)
+    op, ol, ppos = pk["obs_pose"].numpy(), pk["obs_point"].numpy(), pk["obs_ppos"].numpy()
+    for a in range(0, P.n_obs, 7):
+        Wa = H[6 * op[a]:6 * op[a] + 6, 6 * nP + 3 * ol[a]:6 * nP + 3 * ol[a] + 3]
+        assert np.allclose(lin["W"][ppos[a]].reshape(6, 3), Wa, rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.parametrize("lam", [1e-5, 1.0, 100.0])
+def test_schur_band_solve_equals_dense_solve(oracle, lam):
+    """delta from (Schur complement -> band Cholesky -> back-substitution) == dense (H + lam I) d = -g."""
+    s, pk, st, P = small_problem(oracle)
+    poses, points = s["poses_init"], s["points_init"]
+    lin = oracle.ba_linearize(P, poses, points)
+    sch = oracle.ba_schur(P, st["band"], lam, lin)
+    dp, status, _ = oracle.ba_band_solve(sch["Sband"], sch["gs"])
+    assert status == 0
+    dl = oracle.ba_backsub(P, lin, sch["Vinv"], dp)
+    J, r = dense_system(oracle, P, s, pk, poses, points)
+    H = J.T @ J + lam * np.eye(J.shape[1]); g = J.T @ r
+    d = np.linalg.solve(H, -g)
+    nP = P.n_poses
+    assert np.allclose(dp.reshape(-1), d[:6 * nP], rtol=1e-8, atol=1e-10 * np.abs(d).max())
+    assert np.allclose(dl.reshape(-1), d[6 * nP:], rtol=1e-8, atol=1e-10 * np.abs(d).max())
+    # linearised error reported by eval_step == 0.5 |r + J d|^2
+    _, _, lin_err, new_err = oracle.ba_eval_step(P, poses, points, dp, dl)
+    assert np.isclose(lin_err, 0.5 * np.sum((r + J @ d) ** 2), rtol=1e-9)
+    assert lin_err <= lin["err"] * (1 + 1e-12)
+
+
+def test_band_solve_flags_an_indefinite_system(oracle):
+    Sb = np.zeros((3, 2, 36))
+    for i in range(3):
+        Sb[i, 0] = np.eye(6).reshape(-1)
+    Sb[1, 0, 14] = -1.0      # element (2,2) of block (1,1): scalar column 8
+    dp, status, _ = oracle.ba_band_solve(Sb, np.ones((3, 6)))
+    assert status == 6 + 2 + 1
+
+
+def test_lm_recovers_ground_truth_and_decreases_error(oracle):
+    s, pk, st, P = small_problem(oracle, n_kf=50, n_lm=500, obs=100)
+    poses, points, rep = oracle.ba_lm_optimize(P, st["band"], s["poses_init"], s["points_init"])
+    assert rep["status"] == 0 and rep["iterations"] >= 2
+    hist = [rep["initial_error"]] + rep["err_hist"]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(hist, hist[1:]))
+    assert rep["final_error"] < 1e-3 * rep["initial_error"]
+    assert rep["final_error"] <= oracle.ba_error(P, s["poses_gt"], s["points_gt"])
+    assert np.abs(poses[:, 9:] - s["poses_gt"][:, 9:]).max() < 0.03
+    # noiseless measurements -> exact recovery from the same perturbed start
+    s0 = synth.ba_sequence(50, 500, 100, meas_sigma=0.0)
+    pk0 = ba_pack.pack_observations(torch.from_numpy(s0["obs_pose"]), torch.from_numpy(s0["obs_point"]),
+                                    torch.from_numpy(s0["meas"]), 50, len(s0["points_gt"]))
+    st0 = ba_pack.build_structure(pk0)
+    P0 = oracle.BAProblem(pk0, s0["K"], s0["sigma"], (np.array([0], np.int32), s0["poses_gt"][:1], s0["prior_sigmas"][None]))
+    poses0, points0, rep0 = oracle.ba_lm_optimize(P0, st0["band"], s0["poses_init"], s0["points_init"])
+    assert rep0["final_error"] < 1e-12
+    assert np.abs(poses0 - s0["poses_gt"]).max() < 1e-7 and np.abs(points0 - s0["points_gt"]).max() < 1e-5
+
+
+def test_lm_handles_bad_start_by_raising_lambda(oracle):
+    s, pk, st, P = small_problem(oracle, n_kf=20, n_lm=120, obs=40, seed_shift=3)
+    bad = s["points_init"].copy()
+    bad[:, 2] += 3.0       # badly wrong depths (but still in front of the camera)
+    _, _, rep = oracle.ba_lm_optimize(P, st["band"], s["poses_init"], bad)
+    assert rep["tries"] >= rep["outer"]
+    assert rep["final_error"] < rep["initial_error"]
+
+
+def test_pack_and_structure_invariants():
+    s = synth.ba_sequence(30, 200, 50)
+    nL = len(s["points_gt"])
+    perm = np.random.default_rng(0).permutation(len(s["obs_pose"]))
+    pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"][perm]), torch.from_numpy(s["obs_point"][perm]),
+                                   torch.from_numpy(s["meas"][perm]), 30, nL)
+    assert np.array_equal(pk["obs_pose"].numpy(), s["obs_pose"]) and np.array_equal(pk["meas"].numpy(), s["meas"])
+    lidx, ppos = pk["pobs_lidx"].numpy(), pk["obs_ppos"].numpy()
+    assert np.array_equal(ppos[lidx], np.arange(len(lidx)))
+    assert (np.diff(s["obs_pose"][lidx]) >= 0).all()
+    st = ba_pack.build_structure(pk)
+    tl = np.bincount(s["obs_point"])
+    assert st["n_pairs"] == int(np.sum(tl * (tl + 1) // 2))
+    bi, bk = st["blk_i"].numpy(), st["blk_k"].numpy()
+    assert (bi >= bk).all() and (bi - bk).max() == st["band"]
+    pa, pb, ptr = st["pair_a"].numpy(), st["pair_b"].numpy(), st["blk_ptr"].numpy()
+    pose_of_slot = s["obs_pose"][lidx]; point_of_slot = s["obs_point"][lidx]
+    for q in range(0, st["n_blocks"], 11):
+        sl = slice(ptr[q], ptr[q + 1])
+        assert (pose_of_slot[pa[sl]] == bi[q]).all() and (pose_of_slot[pb[sl]] == bk[q]).all()
+        assert (point_of_slot[pa[sl]] == point_of_slot[pb[sl]]).all()
+    with pytest.raises(NotImplementedError):
+        ba_pack.pack_observations(torch.tensor([0, 0]), torch.tensor([1, 1]), torch.zeros(2, 3, dtype=torch.float64), 2, 2)

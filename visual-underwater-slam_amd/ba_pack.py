@@ -1,0 +1,80 @@
+"""Pack stereo observations into the SoA layout of include/vus.h (vus_ba_problem / vus_ba_structure).
+
+This is the vectorised form of the reference's per-observation factor emission loop
+(/root/reference/batch.py:295-305): one `GenericStereoFactor3D(StereoPoint2(uL,uR,v), noise, X(i),
+L(id), K)` per observation becomes one row of `meas` / `obs_pose` / `obs_point`.
+
+Index plumbing only (sorts, prefix sums, gathers) -- written with torch ops so the same code runs on
+the GPU for the 2M-observation problems and on the CPU for tests.  No BA arithmetic happens here.
+"""
+import torch
+
+
+def pack_observations(obs_pose, obs_point, meas, n_poses, n_points):
+    """obs_* : 1-D integer tensors, meas [n_obs,3] float64, any order.  Returns a dict of tensors:
+    L-order (sorted by point, then pose) meas/obs_pose/obs_point/point_ptr/obs_ppos and the P-order
+    pose_ptr/pobs_lidx, plus `perm` (L-order row -> input row)."""
+    dev = obs_pose.device
+    obs_pose = obs_pose.to(torch.int64)
+    obs_point = obs_point.to(torch.int64)
+    n_obs = obs_pose.numel()
+    key = obs_point * n_poses + obs_pose
+    key_sorted, perm = torch.sort(key, stable=True)
+    if n_obs > 1 and bool((key_sorted[1:] == key_sorted[:-1]).any()):
+        raise NotImplementedError("two stereo factors between the same pose and landmark are not supported")
+    op = obs_pose[perm]
+    ol = obs_point[perm]
+    m = meas[perm].contiguous()
+    point_ptr = torch.zeros(n_points + 1, dtype=torch.int64, device=dev)
+    point_ptr[1:] = torch.cumsum(torch.bincount(ol, minlength=n_points), 0)
+    # P-order: stable sort by pose keeps points ascending inside each pose
+    _, pobs_lidx = torch.sort(op, stable=True)
+    obs_ppos = torch.empty_like(pobs_lidx)
+    obs_ppos[pobs_lidx] = torch.arange(n_obs, device=dev)
+    pose_ptr = torch.zeros(n_poses + 1, dtype=torch.int64, device=dev)
+    pose_ptr[1:] = torch.cumsum(torch.bincount(op, minlength=n_poses), 0)
+    i32 = torch.int32
+    return {
+        "n_poses": int(n_poses), "n_points": int(n_points), "n_obs": int(n_obs),
+        "meas": m, "obs_pose": op.to(i32), "obs_point": ol.to(i32), "point_ptr": point_ptr.to(i32),
+        "obs_ppos": obs_ppos.to(i32), "pose_ptr": pose_ptr.to(i32), "pobs_lidx": pobs_lidx.to(i32),
+        "perm": perm,
+    }
+
+
+def build_structure(pk):
+    """Non-zero blocks of the reduced camera system and, per block, the pairs of P-order slots that
+    see a common point (vus_ba_structure)."""
+    dev = pk["obs_pose"].device
+    n_obs, nP = pk["n_obs"], pk["n_poses"]
+    op = pk["obs_pose"].to(torch.int64)
+    ol = pk["obs_point"].to(torch.int64)
+    pptr = pk["point_ptr"].to(torch.int64)
+    ppos = pk["obs_ppos"].to(torch.int64)
+    if n_obs == 0:
+        z = torch.zeros(0, dtype=torch.int32, device=dev)
+        return {"band": 0, "n_blocks": 0, "n_pairs": 0, "blk_ptr": torch.zeros(1, dtype=torch.int32, device=dev),
+                "blk_i": z, "blk_k": z, "pair_a": z, "pair_b": z}
+    ar = torch.arange(n_obs, device=dev)
+    seg_start = pptr[ol]
+    counts = ar - seg_start + 1                       # observation a pairs with seg_start..a
+    total = int(counts.sum().item())
+    if total >= 2 ** 31:
+        raise NotImplementedError(f"{total} co-observation pairs exceed the int32 pair index")
+    a_idx = torch.repeat_interleave(ar, counts)
+    excl = torch.cumsum(counts, 0) - counts
+    b_idx = seg_start[a_idx] + (torch.arange(total, device=dev) - excl[a_idx])
+    pi, pk_ = op[a_idx], op[b_idx]                    # pi >= pk_ (poses ascend inside a point)
+    band = int((pi - pk_).max().item())
+    key = pi * nP + pk_
+    key_sorted, order = torch.sort(key, stable=True)
+    ukey, cnt = torch.unique_consecutive(key_sorted, return_counts=True)
+    blk_ptr = torch.zeros(ukey.numel() + 1, dtype=torch.int64, device=dev)
+    blk_ptr[1:] = torch.cumsum(cnt, 0)
+    i32 = torch.int32
+    return {
+        "band": band, "n_blocks": int(ukey.numel()), "n_pairs": total,
+        "blk_ptr": blk_ptr.to(i32), "blk_i": torch.div(ukey, nP, rounding_mode="floor").to(i32),
+        "blk_k": (ukey % nP).to(i32),
+        "pair_a": ppos[a_idx[order]].to(i32).contiguous(), "pair_b": ppos[b_idx[order]].to(i32).contiguous(),
+    }

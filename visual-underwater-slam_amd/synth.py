@@ -84,3 +84,121 @@ def stereo_frames(t0, n_frames, H=720, W=1280, xp=np, device=None, seed=SEED, ca
             pair.append(img.astype(np.uint8) if xp is np else img.to(xp.uint8))
         out.append(np.stack(pair) if xp is np else xp.stack(pair))
     return np.stack(out) if xp is np else xp.stack(out)
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic stereo bundle-adjustment sequences ("Synthetic BA input").
+# Camera constants are the reference's: /root/reference/batch.py:110-118.
+BASELINE_M = 0.063
+INTRINSIC = (1827.0, 1827.5999755859375, 968.9000244140625, 561.4000244140625)  # fx, fy, cx, cy
+RES_X, RES_Y = 1920, 1080
+STEREO_SIGMA = 10.0
+PRIOR_SIGMAS = (0.1, 0.1, 0.1, 0.3, 0.3, 0.3)
+
+
+def _hash_uniform(idx, key):
+    """uniform (0,1) doubles from a counter array and a scalar key (numpy)."""
+    h = _mix32(np.asarray(idx, dtype=np.int64) ^ _mix32_scalar(key))
+    h2 = _mix32(h ^ 0x5BD1E995)
+    return ((h * 4294967296.0 + h2) + 0.5) / 18446744073709551616.0
+
+
+def _hash_normal(n, key):
+    i = np.arange(n, dtype=np.int64)
+    u1 = _hash_uniform(i, key)
+    u2 = _hash_uniform(i, key ^ 0x68E31DA4)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def _rodrigues(w):
+    th = np.linalg.norm(w)
+    K = np.array([[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]])
+    if th < 1e-12:
+        return np.eye(3) + K
+    return np.eye(3) + np.sin(th) / th * K + (1 - np.cos(th)) / th ** 2 * K @ K
+
+
+def ba_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, line_len=None, kf_step=0.25, line_step=0.8,
+                pose_sigma_t=0.05, pose_sigma_r=0.01, meas_sigma=1.0):
+    """Lawn-mower sweep of a down-looking stereo rig at constant altitude over a slab of landmarks.
+
+    Returns a dict of numpy arrays:
+      poses_gt / poses_init [n_kf,12] (row-major R, then t; camera-to-world),
+      points_gt / points_init [n_points,3],
+      obs_pose, obs_point [n_obs] int32 and meas [n_obs,3] (uL,uR,v), sorted by (point, pose),
+      K [6] (fx,fy,0,cx,cy,b), sigma, prior_sigmas.
+    Every keyframe observes its (up to) obs_per_kf visible landmarks nearest the image centre;
+    landmarks nobody observes are dropped and the rest renumbered.
+    """
+    fx, fy, cx, cy = INTRINSIC
+    if line_len is None:
+        line_len = max(5, int(round(np.sqrt(n_kf * line_step / kf_step))))
+        line_len = min(line_len, 50)
+    n_lines = (n_kf + line_len - 1) // line_len
+    # trajectory: optical axis = world +Z, camera x = direction of travel
+    poses = np.zeros((n_kf, 12))
+    for i in range(n_kf):
+        ln, k = divmod(i, line_len)
+        fwd = ln % 2 == 0
+        x = (k if fwd else line_len - 1 - k) * kf_step
+        y = ln * line_step
+        yaw = 0.0 if fwd else np.pi
+        c, s = np.cos(yaw), np.sin(yaw)
+        poses[i, :9] = np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]]).reshape(-1)
+        poses[i, 9:] = (x, y, 0.0)
+    # landmarks: uniform over the swept footprint (+ margin), depth 2..6 m
+    ext_x, ext_y = (line_len - 1) * kf_step, (n_lines - 1) * line_step
+    j = np.arange(n_lm, dtype=np.int64)
+    pts = np.stack([-2.0 + (ext_x + 4.0) * _hash_uniform(j, seed ^ 0x1111),
+                    -1.2 + (ext_y + 2.4) * _hash_uniform(j, seed ^ 0x2222),
+                    2.0 + 4.0 * _hash_uniform(j, seed ^ 0x3333)], 1)
+    obs_p, obs_l, meas = [], [], []
+    for i in range(n_kf):
+        R = poses[i, :9].reshape(3, 3)
+        q = (pts - poses[i, 9:]) @ R          # rows: R^T (p - t)
+        z = q[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            uL = cx + fx * q[:, 0] / z
+            uR = cx + fx * (q[:, 0] - BASELINE_M) / z
+            v = cy + fy * q[:, 1] / z
+        vis = (z > 0.5) & (uL >= 0) & (uL < RES_X) & (uR >= 0) & (uR < RES_X) & (v >= 0) & (v < RES_Y)
+        idx = np.nonzero(vis)[0]
+        if len(idx) > obs_per_kf:
+            d2 = (uL[idx] - cx) ** 2 + (v[idx] - cy) ** 2
+            idx = idx[np.argsort(d2, kind="stable")[:obs_per_kf]]
+            idx.sort()
+        obs_p.append(np.full(len(idx), i, np.int32))
+        obs_l.append(idx.astype(np.int32))
+        meas.append(np.stack([uL[idx], uR[idx], v[idx]], 1))
+    obs_p, obs_l, meas = np.concatenate(obs_p), np.concatenate(obs_l), np.concatenate(meas)
+    used = np.unique(obs_l)
+    remap = -np.ones(n_lm, np.int64)
+    remap[used] = np.arange(len(used))
+    obs_l = remap[obs_l].astype(np.int32)
+    pts = pts[used]
+    order = np.lexsort((obs_p, obs_l))
+    obs_p, obs_l, meas = obs_p[order], obs_l[order], meas[order]
+    n_obs = len(obs_p)
+    meas = meas + meas_sigma * _hash_normal(3 * n_obs, seed ^ 0x4444).reshape(n_obs, 3)
+    # initial estimate: perturbed poses (X0 exact = its prior, like the odometry prior of batch.py:281-283)
+    poses_init = poses.copy()
+    nt = pose_sigma_t * _hash_normal(3 * n_kf, seed ^ 0x5555).reshape(n_kf, 3)
+    nr = pose_sigma_r * _hash_normal(3 * n_kf, seed ^ 0x6666).reshape(n_kf, 3)
+    for i in range(1, n_kf):
+        R = poses[i, :9].reshape(3, 3) @ _rodrigues(nr[i])
+        poses_init[i, :9] = R.reshape(-1)
+        poses_init[i, 9:] = poses[i, 9:] + nt[i]
+    # landmark initial estimate: stereo triangulation of the first observation from the perturbed pose
+    first = np.concatenate([[0], np.nonzero(np.diff(obs_l))[0] + 1])
+    m0, p0 = meas[first], obs_p[first]
+    disp = np.maximum(m0[:, 0] - m0[:, 1], 0.5)
+    zc = fx * BASELINE_M / disp
+    cam = np.stack([(m0[:, 0] - cx) * zc / fx, (m0[:, 2] - cy) * zc / fy, zc], 1)
+    Rm = poses_init[p0, :9].reshape(-1, 3, 3)
+    pts_init = np.einsum("nij,nj->ni", Rm, cam) + poses_init[p0, 9:]
+    return {
+        "poses_gt": poses, "poses_init": poses_init, "points_gt": pts, "points_init": pts_init,
+        "obs_pose": obs_p.astype(np.int32), "obs_point": obs_l.astype(np.int32), "meas": meas,
+        "K": np.array([fx, fy, 0.0, cx, cy, BASELINE_M]), "sigma": STEREO_SIGMA,
+        "prior_sigmas": np.array(PRIOR_SIGMAS), "line_len": line_len,
+    }
