@@ -147,11 +147,12 @@ typedef struct vus_ba_structure {
  *   gl  [n_points,3] sum H2^T r
  *   Hpp [n_poses,36] sum H1^T H1 + prior information;  gp [n_poses,6] sum H1^T r + prior part
  *   err [1]          0.5 * sum |whitened residual|^2 over stereo factors and priors
+ *   work             scratch of at least vus_ba_work_doubles(P) doubles (deterministic reductions)
  * Stereo residual/Jacobians follow gtsam::GenericStereoFactor / StereoCamera::project2
  * (cheirality z <= 0: residual 2*fx on all three rows, zero Jacobians). */
 int vus_ba_linearize(const vus_ba_problem* P, const double* poses, const double* points,
                      double* W, double* V, double* gl, double* Hpp, double* gp, double* err,
-                     void* stream);
+                     double* work, void* stream);
 
 /* Damped landmark elimination for one lambda (lambda*I damping, gtsam diagonalDamping=false):
  *   Vinv [n_points,6] = (V + lambda I)^-1 (upper triangle);  Y [n_obs,18] = W Vinv (P-order);
@@ -174,11 +175,14 @@ int vus_ba_backsub(const vus_ba_problem* P, const double* W, const double* Vinv,
  * out[1] = nonlinear error at the new values (stereo factors + priors). */
 int vus_ba_eval_step(const vus_ba_problem* P, const double* poses, const double* points,
                      const double* dp, const double* dl, double* new_poses, double* new_points,
-                     double* out, void* stream);
+                     double* out, double* work, void* stream);
 
 /* err[0] = 0.5 * sum |whitened residual|^2 at (poses, points): NonlinearFactorGraph.error(). */
 int vus_ba_error(const vus_ba_problem* P, const double* poses, const double* points, double* err,
-                 void* stream);
+                 double* work, void* stream);
+
+/* Number of doubles the `work` scratch of the calls above must hold for problem P (host-side, no launch). */
+long long vus_ba_work_doubles(const vus_ba_problem* P);
 
 #ifdef __cplusplus
 }

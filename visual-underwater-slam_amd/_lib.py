@@ -17,6 +17,13 @@ SIGNATURES = {
     "vus_orient_rbrief": [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P],
     "vus_hamming_match": [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "vus_triangulate": [_P, c_int, _P, _P, _P, _P],
+    # bundle adjustment (struct arguments are passed by address)
+    "vus_ba_linearize": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "vus_ba_schur": [_P, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "vus_ba_band_solve": [_P, c_int, c_int, _P, _P, _P, _P],
+    "vus_ba_backsub": [_P, _P, _P, _P, _P, _P, _P],
+    "vus_ba_eval_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "vus_ba_error": [_P, _P, _P, _P, _P, _P],
 }
 
 
@@ -46,6 +53,8 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.argtypes = argtypes
         fn.restype = c_int
+    lib.vus_ba_work_doubles.argtypes = [_P]
+    lib.vus_ba_work_doubles.restype = ctypes.c_longlong
     _lib = lib
     return lib
 

@@ -1,0 +1,254 @@
+"""Host side of the stereo bundle adjustment: device-resident problem, workspace, and the
+Levenberg-Marquardt control loop that drives the HIP kernels of csrc/ba.hip through the C ABI.
+
+Mirrors what `gtsam.LevenbergMarquardtOptimizer(graph, initial, params).optimize()` does at
+/root/reference/batch.py:337 (GTSAM's iterate / tryLambda / checkConvergence logic with the default
+LevenbergMarquardtParams), for graphs of GenericStereoFactor3D + PriorFactorPose3 factors.  All
+arithmetic (residuals, Jacobians, Schur complement, band Cholesky, retraction, errors) runs on the
+GPU; this file only sequences launches and reads back three scalars per lambda trial.
+"""
+import ctypes
+import math
+import time
+from ctypes import c_double, c_int, c_void_p
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import torch
+
+from . import _lib, ba_pack
+
+
+class _CProblem(ctypes.Structure):
+    _fields_ = [("n_poses", c_int), ("n_points", c_int), ("n_obs", c_int), ("n_priors", c_int),
+                ("K", c_void_p), ("inv_sigma", c_double), ("meas", c_void_p), ("obs_pose", c_void_p),
+                ("obs_point", c_void_p), ("point_ptr", c_void_p), ("obs_ppos", c_void_p),
+                ("pose_ptr", c_void_p), ("pobs_lidx", c_void_p), ("prior_pose", c_void_p),
+                ("prior_T", c_void_p), ("prior_w", c_void_p)]
+
+
+class _CStructure(ctypes.Structure):
+    _fields_ = [("band", c_int), ("n_blocks", c_int), ("n_pairs", c_int), ("blk_ptr", c_void_p),
+                ("blk_i", c_void_p), ("blk_k", c_void_p), ("pair_a", c_void_p), ("pair_b", c_void_p)]
+
+
+
+
+@dataclass
+class LMParams:
+    """gtsam.LevenbergMarquardtParams() defaults."""
+    lambdaInitial: float = 1e-5
+    lambdaFactor: float = 10.0
+    lambdaUpperBound: float = 1e5
+    lambdaLowerBound: float = 0.0
+    minModelFidelity: float = 1e-3
+    maxIterations: int = 100
+    relativeErrorTol: float = 1e-5
+    absoluteErrorTol: float = 1e-5
+    errorTol: float = 0.0
+    diagonalDamping: bool = False
+    useFixedLambdaFactor: bool = True
+
+
+@dataclass
+class LMReport:
+    iterations: int = 0          # accepted steps (gtsam iterations())
+    outer: int = 0               # linearisations
+    tries: int = 0               # linear solves
+    status: int = 1              # 0 converged, 1 max iterations, 2 lambda upper bound
+    initial_error: float = 0.0
+    final_error: float = 0.0
+    final_lambda: float = 0.0
+    err_hist: List[float] = field(default_factory=list)
+    lambda_hist: List[float] = field(default_factory=list)
+    seconds: float = 0.0
+    setup_seconds: float = 0.0
+
+
+def _i32(t):
+    return t.to(torch.int32).contiguous()
+
+
+class StereoBAProblem:
+    """Packed, device-resident stereo BA problem (vus_ba_problem + vus_ba_structure)."""
+
+    def __init__(self, obs_pose, obs_point, meas, n_poses, n_points, K, sigma, prior_pose=None,
+                 prior_T=None, prior_sigmas=None, device="cuda:0"):
+        _lib.require_gpu()
+        _lib.load()
+        dev = torch.device(device)
+        t0 = time.perf_counter()
+
+        def to_dev(x, dt):
+            return torch.as_tensor(x).to(device=dev, dtype=dt).contiguous()
+        pk = ba_pack.pack_observations(to_dev(obs_pose, torch.int64), to_dev(obs_point, torch.int64),
+                                       to_dev(meas, torch.float64), n_poses, n_points)
+        st = ba_pack.build_structure(pk)
+        self.pk, self.st = pk, st
+        self.device = dev
+        self.n_poses, self.n_points, self.n_obs = int(n_poses), int(n_points), pk["n_obs"]
+        self.band = st["band"]
+        self.K = to_dev(K, torch.float64)
+        assert self.K.numel() == 6
+        self.sigma = float(sigma)
+        if prior_pose is None or len(prior_pose) == 0:
+            self.prior_pose = torch.zeros(0, dtype=torch.int32, device=dev)
+            self.prior_T = torch.zeros((0, 12), dtype=torch.float64, device=dev)
+            self.prior_w = torch.zeros((0, 6), dtype=torch.float64, device=dev)
+        else:
+            self.prior_pose = to_dev(prior_pose, torch.int32)
+            self.prior_T = to_dev(prior_T, torch.float64).reshape(-1, 12)
+            self.prior_w = (1.0 / to_dev(prior_sigmas, torch.float64).reshape(-1, 6)).contiguous()
+        n_pr = self.prior_pose.numel()
+        p = _lib.ptr
+        self.c_problem = _CProblem(self.n_poses, self.n_points, self.n_obs, n_pr, p(self.K), 1.0 / self.sigma,
+                                   p(pk["meas"]), p(pk["obs_pose"]), p(pk["obs_point"]), p(pk["point_ptr"]),
+                                   p(pk["obs_ppos"]), p(pk["pose_ptr"]), p(pk["pobs_lidx"]),
+                                   p(self.prior_pose) if n_pr else None, p(self.prior_T) if n_pr else None,
+                                   p(self.prior_w) if n_pr else None)
+        self.c_structure = _CStructure(st["band"], st["n_blocks"], st["n_pairs"], p(st["blk_ptr"]), p(st["blk_i"]),
+                                       p(st["blk_k"]), p(st["pair_a"]), p(st["pair_b"]))
+        torch.cuda.synchronize(dev)
+        self.setup_seconds = time.perf_counter() - t0
+
+
+class StereoBASolver:
+    """Workspace + LM loop.  Buffers are allocated once; optimize() allocates nothing."""
+
+    def __init__(self, problem: StereoBAProblem):
+        self.P = problem
+        dev, nP, nL, nO, B = problem.device, problem.n_poses, problem.n_points, problem.n_obs, problem.band
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.W = torch.empty((nO, 18), **f64)
+        self.Y = torch.empty((nO, 18), **f64)
+        self.V = torch.empty((nL, 6), **f64)
+        self.Vinv = torch.empty((nL, 6), **f64)
+        self.gl = torch.empty((nL, 3), **f64)
+        self.dl = torch.empty((nL, 3), **f64)
+        self.Hpp = torch.empty((nP, 36), **f64)
+        self.gp = torch.empty((nP, 6), **f64)
+        self.gs = torch.empty((nP, 6), **f64)
+        self.dp = torch.empty((nP, 6), **f64)
+        self.Sband = torch.empty((nP, B + 1, 36), **f64)
+        self.new_poses = torch.empty((nP, 12), **f64)
+        self.new_points = torch.empty((nL, 3), **f64)
+        self.work = torch.empty((2 * (nL + 1) + 8,), **f64)
+        self.scal = torch.zeros((4,), **f64)          # [0] linearise error, [1] lin. error at step, [2] new error
+        self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
+
+    # -- single kernels (also used by the parity tests) ------------------------------------------
+    def _pp(self):
+        return ctypes.addressof(self.P.c_problem)
+
+    def error(self, poses, points) -> float:
+        _lib.call("vus_ba_error", self._pp(), _lib.ptr(poses), _lib.ptr(points), _lib.ptr(self.scal),
+                  _lib.ptr(self.work), _lib.current_stream_ptr())
+        return float(self.scal[0].item())
+
+    def linearize(self, poses, points):
+        p = _lib.ptr
+        _lib.call("vus_ba_linearize", self._pp(), p(poses), p(points), p(self.W), p(self.V), p(self.gl),
+                  p(self.Hpp), p(self.gp), p(self.scal), p(self.work), _lib.current_stream_ptr())
+
+    def schur(self, lam: float):
+        p = _lib.ptr
+        _lib.call("vus_ba_schur", self._pp(), ctypes.addressof(self.P.c_structure), float(lam), p(self.W), p(self.V),
+                  p(self.gl), p(self.Hpp), p(self.gp), p(self.Vinv), p(self.Y), p(self.Sband), p(self.gs),
+                  _lib.current_stream_ptr())
+
+    def band_solve(self):
+        p = _lib.ptr
+        _lib.call("vus_ba_band_solve", p(self.Sband), self.P.n_poses, self.P.band, p(self.gs), p(self.dp),
+                  p(self.status), _lib.current_stream_ptr())
+
+    def backsub(self):
+        p = _lib.ptr
+        _lib.call("vus_ba_backsub", self._pp(), p(self.W), p(self.Vinv), p(self.gl), p(self.dp), p(self.dl),
+                  _lib.current_stream_ptr())
+
+    def eval_step(self, poses, points):
+        p = _lib.ptr
+        _lib.call("vus_ba_eval_step", self._pp(), p(poses), p(points), p(self.dp), p(self.dl), p(self.new_poses),
+                  p(self.new_points), p(self.scal[1:]), p(self.work), _lib.current_stream_ptr())
+
+    # -- Levenberg-Marquardt ----------------------------------------------------------------------
+    def optimize(self, poses: torch.Tensor, points: torch.Tensor, params: Optional[LMParams] = None,
+                 extra_error=None):
+        """poses [nP,12], points [nL,3] float64 on the GPU; returns optimised copies and an LMReport.
+        `extra_error` is a constant added to every error (factors the solver does not touch)."""
+        prm = params or LMParams()
+        if prm.diagonalDamping:
+            raise NotImplementedError("diagonalDamping=True is not implemented (gtsam default is False)")
+        if not prm.useFixedLambdaFactor:
+            raise NotImplementedError("useFixedLambdaFactor=False is not implemented (gtsam default is True)")
+        extra = float(extra_error or 0.0)
+        poses = poses.to(torch.float64).contiguous().clone()
+        points = points.to(torch.float64).contiguous().clone()
+        rep = LMReport(setup_seconds=self.P.setup_seconds)
+        torch.cuda.synchronize(self.P.device)
+        t0 = time.perf_counter()
+        lam = prm.lambdaInitial
+        current = self.error(poses, points) + extra
+        rep.initial_error = current
+        if current <= prm.errorTol or prm.maxIterations <= 0:
+            rep.status, rep.final_error, rep.final_lambda = 0, current, lam
+            return poses, points, rep
+        while rep.iterations < prm.maxIterations:
+            self.linearize(poses, points)                         # iterate(): linearise once
+            new_error, stop_search, accepted = current, False, False
+            lin0 = None
+            while True:                                           # tryLambda
+                self.schur(lam)
+                self.band_solve()
+                self.backsub()
+                self.eval_step(poses, points)
+                sc = self.scal.cpu()                              # one sync per trial
+                status = int(self.status.item())
+                rep.tries += 1
+                if lin0 is None:
+                    lin0 = float(sc[0]) + extra
+                success = False
+                if status == 0 and math.isfinite(float(sc[1])) and math.isfinite(float(sc[2])):
+                    lin_change = lin0 - (float(sc[1]) + extra)
+                    if lin_change >= 0.0:
+                        new_err = float(sc[2]) + extra
+                        cost_change = current - new_err
+                        if lin_change > 2.220446049250313e-16 * lin0:
+                            success = cost_change / lin_change > prm.minModelFidelity
+                        if abs(cost_change) < prm.relativeErrorTol * current:
+                            stop_search = True
+                        if success:
+                            poses, self.new_poses = self.new_poses, poses
+                            points, self.new_points = self.new_points, points
+                            new_error = new_err
+                if success:
+                    lam = max(prm.lambdaLowerBound, lam / prm.lambdaFactor)
+                    accepted = True
+                    break
+                if stop_search:
+                    break
+                lam *= prm.lambdaFactor
+                if lam >= prm.lambdaUpperBound:
+                    rep.status = 2
+                    break
+            rep.err_hist.append(new_error)
+            rep.lambda_hist.append(lam)
+            rep.outer += 1
+            rep.iterations += int(accepted)
+            if new_error <= prm.errorTol:
+                converged = True
+            else:
+                abs_dec = current - new_error
+                converged = (abs_dec / current <= prm.relativeErrorTol) or (abs_dec <= prm.absoluteErrorTol)
+            current = new_error
+            if rep.status == 2:
+                break
+            if converged:
+                rep.status = 0
+                break
+            if not math.isfinite(current):
+                break
+        torch.cuda.synchronize(self.P.device)
+        rep.seconds = time.perf_counter() - t0
+        rep.final_error, rep.final_lambda = current, lam
+        return poses, points, rep

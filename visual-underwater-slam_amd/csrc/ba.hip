@@ -1,0 +1,874 @@
+// ba.hip -- stereo bundle-adjustment kernels for gfx950 (MI355X), fp64.
+//
+// What gtsam.LevenbergMarquardtOptimizer(graph, values, params).optimize() (reference batch.py:337)
+// spends its time on for a graph of GenericStereoFactor3D factors (batch.py:300-305) with
+// PriorFactorPose3 gauge priors (batch.py:281): per-factor residual/Jacobian evaluation, damped
+// normal equations, landmark Schur complement, reduced camera solve, back-substitution, retraction
+// and error evaluation.  The Levenberg-Marquardt control flow stays on the host (ba.py).
+//
+// Layout (include/vus.h): observations in L-order (point-major) and P-order (pose-major) with both
+// permutations precomputed; per-observation 6x3 products W, Y in P-order so that every block of the
+// reduced camera system reads two compact per-pose segments.
+//
+// Kernel map (all deterministic: no float atomics, fixed-order wave/LDS reductions):
+//   lin_points   wave / point      r, H1, H2 -> W (scatter to P-order), V, gl, error partial
+//   lin_poses    workgroup / pose  r, H1 (recomputed, never stored) -> Hpp, gp
+//   priors       one lane          PriorFactorPose3 information / gradient / error
+//   vinv, ymul   thread / point, thread / obs   (V + lambda I)^-1,  Y = W Vinv
+//   schur_init / schur_blocks / schur_rhs       S = Hpp + lambda I - sum Y W^T (wave per 6x6 block,
+//                60 lanes = 5 pair slices x 12 three-element strips), gs = gp - sum Y gl
+//   chol_panel / chol_trsm / chol_update / chol_backsolve   block-band Cholesky, 8-pose panels
+//   backsub      wave / point      dl = -Vinv (gl + sum W^T dp)
+//   retract, eval_points, error_points, reduce_partials
+#include "vus_common.h"
+
+namespace {
+
+constexpr double kEps = 2.220446049250313e-16;
+constexpr double kPi = 3.14159265358979323846;
+
+// ---------------------------------------------------------------------------------------------
+// Lie-group helpers (gtsam Pose3 / Rot3 conventions; mirrored independently by the CPU oracle)
+__device__ void so3_expmap(const double* w, double* R) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  const double Wx[9] = {0, -w[2], w[1], w[2], 0, -w[0], -w[1], w[0], 0};
+  if (th2 <= kEps) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) R[i] = Wx[i] + (i % 4 == 0 ? 1.0 : 0.0);
+    return;
+  }
+  const double th = sqrt(th2);
+  const double s = sin(th) / th;
+  const double sh = sin(0.5 * th);
+  const double c = 2.0 * sh * sh / th2;
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) {
+      double ww = 0;
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ww += Wx[3 * r + k] * Wx[3 * k + cc];
+      R[3 * r + cc] = (r == cc ? 1.0 : 0.0) + s * Wx[3 * r + cc] + c * ww;
+    }
+}
+
+__device__ void so3_logmap(const double* R, double* w) {
+  const double tr = R[0] + R[4] + R[8];
+  if (tr + 1.0 < 1e-10) {
+    if (fabs(R[8] + 1.0) > 1e-5) {
+      double k = kPi / sqrt(2.0 + 2.0 * R[8]);
+      w[0] = k * R[2]; w[1] = k * R[5]; w[2] = k * (1.0 + R[8]);
+    } else if (fabs(R[4] + 1.0) > 1e-5) {
+      double k = kPi / sqrt(2.0 + 2.0 * R[4]);
+      w[0] = k * R[1]; w[1] = k * (1.0 + R[4]); w[2] = k * R[7];
+    } else {
+      double k = kPi / sqrt(2.0 + 2.0 * R[0]);
+      w[0] = k * (1.0 + R[0]); w[1] = k * R[3]; w[2] = k * R[6];
+    }
+    return;
+  }
+  double mag;
+  const double tr3 = tr - 3.0;
+  if (tr3 < -1e-7) {
+    double th = acos((tr - 1.0) / 2.0);
+    mag = th / (2.0 * sin(th));
+  } else {
+    mag = 0.5 - tr3 / 12.0;
+  }
+  w[0] = mag * (R[7] - R[5]);
+  w[1] = mag * (R[2] - R[6]);
+  w[2] = mag * (R[3] - R[1]);
+}
+
+// out = T * Exp(xi)
+__device__ void pose_retract(const double* T, const double* xi, double* out) {
+  double Re[9], te[3];
+  so3_expmap(xi, Re);
+  const double* w = xi;
+  const double* v = xi + 3;
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  if (th2 > kEps) {
+    double wv = w[0] * v[0] + w[1] * v[1] + w[2] * v[2];
+    double c[3] = {w[1] * v[2] - w[2] * v[1], w[2] * v[0] - w[0] * v[2], w[0] * v[1] - w[1] * v[0]};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      double Rc = Re[3 * r] * c[0] + Re[3 * r + 1] * c[1] + Re[3 * r + 2] * c[2];
+      te[r] = (c[r] - Rc + w[r] * wv) / th2;
+    }
+  } else {
+    te[0] = v[0]; te[1] = v[1]; te[2] = v[2];
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      out[3 * r + c] = T[3 * r] * Re[c] + T[3 * r + 1] * Re[3 + c] + T[3 * r + 2] * Re[6 + c];
+    out[9 + r] = T[9 + r] + (T[3 * r] * te[0] + T[3 * r + 1] * te[1] + T[3 * r + 2] * te[2]);
+  }
+}
+
+// xi = Logmap(T^-1 * T2)
+__device__ void pose_local(const double* T, const double* T2, double* xi) {
+  double R[9], t[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R[3 * r + c] = T[r] * T2[c] + T[3 + r] * T2[3 + c] + T[6 + r] * T2[6 + c];
+    t[r] = T[r] * (T2[9] - T[9]) + T[3 + r] * (T2[10] - T[10]) + T[6 + r] * (T2[11] - T[11]);
+  }
+  double w[3];
+  so3_logmap(R, w);
+  const double th = sqrt(w[0] * w[0] + w[1] * w[1] + w[2] * w[2]);
+  xi[0] = w[0]; xi[1] = w[1]; xi[2] = w[2];
+  if (th < 1e-10) {
+    xi[3] = t[0]; xi[4] = t[1]; xi[5] = t[2];
+    return;
+  }
+  const double k[3] = {w[0] / th, w[1] / th, w[2] / th};
+  const double WT[3] = {k[1] * t[2] - k[2] * t[1], k[2] * t[0] - k[0] * t[2], k[0] * t[1] - k[1] * t[0]};
+  const double WWT[3] = {k[1] * WT[2] - k[2] * WT[1], k[2] * WT[0] - k[0] * WT[2], k[0] * WT[1] - k[1] * WT[0]};
+  const double tn = tan(0.5 * th);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) xi[3 + r] = t[r] - (0.5 * th) * WT[r] + (1.0 - th / (2.0 * tn)) * WWT[r];
+}
+
+struct Calib {
+  double fx, fy, cx, cy, b, w;
+};
+
+__device__ __forceinline__ Calib load_calib(const double* K, double inv_sigma) {
+  return Calib{K[0], K[1], K[3], K[4], K[5], inv_sigma};
+}
+
+// GenericStereoFactor3D: whitened residual and (optionally) Jacobians.
+// gtsam StereoCamera::project2: q = R^T (p - t); z <= 0 -> cheirality: residual 2 fx, zero Jacobians.
+template <bool WITH_H1, bool WITH_H2>
+__device__ __forceinline__ void stereo_factor(const double* __restrict__ T, const double* __restrict__ p,
+                                              const double* __restrict__ m, const Calib& K, double* r,
+                                              double* H1, double* H2) {
+  const double d0 = p[0] - T[9], d1 = p[1] - T[10], d2 = p[2] - T[11];
+  const double x = T[0] * d0 + T[3] * d1 + T[6] * d2;
+  const double y = T[1] * d0 + T[4] * d1 + T[7] * d2;
+  const double z = T[2] * d0 + T[5] * d1 + T[8] * d2;
+  if (z <= 0.0) {
+    r[0] = r[1] = r[2] = 2.0 * K.fx * K.w;
+    if (WITH_H1)
+#pragma unroll
+      for (int k = 0; k < 18; ++k) H1[k] = 0.0;
+    if (WITH_H2)
+#pragma unroll
+      for (int k = 0; k < 9; ++k) H2[k] = 0.0;
+    return;
+  }
+  const double d = 1.0 / z;
+  r[0] = (K.cx + d * K.fx * x - m[0]) * K.w;
+  r[1] = (K.cx + d * K.fx * (x - K.b) - m[1]) * K.w;
+  r[2] = (K.cy + d * K.fy * y - m[2]) * K.w;
+  if (!WITH_H1 && !WITH_H2) return;
+  const double J[9] = {K.w * d * K.fx, 0.0, -K.w * d * d * K.fx * x,
+                       K.w * d * K.fx, 0.0, -K.w * d * d * K.fx * (x - K.b),
+                       0.0, K.w * d * K.fy, -K.w * d * d * K.fy * y};
+  if (WITH_H2)
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        H2[3 * rr + c] = J[3 * rr] * T[3 * c] + J[3 * rr + 1] * T[3 * c + 1] + J[3 * rr + 2] * T[3 * c + 2];
+  if (WITH_H1) {
+    const double Q[9] = {0, -z, y, z, 0, -x, -y, x, 0};
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        H1[6 * rr + c] = J[3 * rr] * Q[c] + J[3 * rr + 1] * Q[3 + c] + J[3 * rr + 2] * Q[6 + c];
+        H1[6 * rr + 3 + c] = -J[3 * rr + c];
+      }
+  }
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+__device__ __forceinline__ void load12(const double* __restrict__ src, double* dst) {
+#pragma unroll
+  for (int k = 0; k < 12; ++k) dst[k] = src[k];
+}
+
+__device__ __forceinline__ double sym3(const double* v, int r, int c) {
+  // upper-triangle storage xx,xy,xz,yy,yz,zz
+  const int lo = r < c ? r : c, hi = r < c ? c : r;
+  return v[lo == 0 ? hi : (lo == 1 ? 2 + hi : 5)];
+}
+
+// ---------------------------------------------------------------------------------------------
+// linearisation
+__global__ __launch_bounds__(256) void lin_points_kernel(vus_ba_problem P, const double* __restrict__ poses,
+                                                         const double* __restrict__ points,
+                                                         double* __restrict__ W, double* __restrict__ V,
+                                                         double* __restrict__ gl, double* __restrict__ err_part) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= P.n_points) return;
+  const Calib K = load_calib(P.K, P.inv_sigma);
+  const int a0 = P.point_ptr[j], a1 = P.point_ptr[j + 1];
+  const double p[3] = {points[3 * j], points[3 * j + 1], points[3 * j + 2]};
+  double v[6] = {0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0}, e = 0;
+  for (int a = a0 + lane; a < a1; a += 64) {
+    double T[12], r[3], H1[18], H2[9];
+    load12(poses + 12 * (size_t)P.obs_pose[a], T);
+    const double m[3] = {P.meas[3 * (size_t)a], P.meas[3 * (size_t)a + 1], P.meas[3 * (size_t)a + 2]};
+    stereo_factor<true, true>(T, p, m, K, r, H1, H2);
+    e += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    double* Wa = W + 18 * (size_t)P.obs_ppos[a];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) Wa[3 * rr + c] = H1[rr] * H2[c] + H1[6 + rr] * H2[3 + c] + H1[12 + rr] * H2[6 + c];
+    int u = 0;
+#pragma unroll
+    for (int rr = 0; rr < 3; ++rr)
+#pragma unroll
+      for (int c = rr; c < 3; ++c, ++u) v[u] += H2[rr] * H2[c] + H2[3 + rr] * H2[3 + c] + H2[6 + rr] * H2[6 + c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) g[c] += H2[c] * r[0] + H2[3 + c] * r[1] + H2[6 + c] * r[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 6; ++k) v[k] = wave_sum(v[k]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) g[k] = wave_sum(g[k]);
+  e = wave_sum(e);
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) V[6 * (size_t)j + k] = v[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) gl[3 * (size_t)j + k] = g[k];
+    err_part[j] = e;
+  }
+}
+
+__global__ __launch_bounds__(256) void lin_poses_kernel(vus_ba_problem P, const double* __restrict__ poses,
+                                                        const double* __restrict__ points,
+                                                        double* __restrict__ Hpp, double* __restrict__ gp) {
+  __shared__ double s_part[4][27];
+  const int i = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const Calib K = load_calib(P.K, P.inv_sigma);
+  double T[12];
+  load12(poses + 12 * (size_t)i, T);
+  double acc[27];
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = 0;
+  const int s0 = P.pose_ptr[i], s1 = P.pose_ptr[i + 1];
+  for (int s = s0 + (int)threadIdx.x; s < s1; s += 256) {
+    const int a = P.pobs_lidx[s];
+    const int j = P.obs_point[a];
+    const double p[3] = {points[3 * (size_t)j], points[3 * (size_t)j + 1], points[3 * (size_t)j + 2]};
+    const double m[3] = {P.meas[3 * (size_t)a], P.meas[3 * (size_t)a + 1], P.meas[3 * (size_t)a + 2]};
+    double r[3], H1[18];
+    stereo_factor<true, false>(T, p, m, K, r, H1, nullptr);
+    int u = 0;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr)
+#pragma unroll
+      for (int c = rr; c < 6; ++c, ++u) acc[u] += H1[rr] * H1[c] + H1[6 + rr] * H1[6 + c] + H1[12 + rr] * H1[12 + c];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) acc[21 + rr] += H1[rr] * r[0] + H1[6 + rr] * r[1] + H1[12 + rr] * r[2];
+  }
+#pragma unroll
+  for (int k = 0; k < 27; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane == 0)
+#pragma unroll
+    for (int k = 0; k < 27; ++k) s_part[wave][k] = acc[k];
+  __syncthreads();
+  if (threadIdx.x < 36) {
+    const int rr = threadIdx.x / 6, c = threadIdx.x % 6;
+    const int lo = rr < c ? rr : c, hi = rr < c ? c : rr;
+    const int u = lo * 6 - lo * (lo - 1) / 2 + (hi - lo);  // index in the row-wise upper triangle
+    Hpp[36 * (size_t)i + threadIdx.x] = ((s_part[0][u] + s_part[1][u]) + s_part[2][u]) + s_part[3][u];
+  } else if (threadIdx.x < 42) {
+    const int u = 21 + threadIdx.x - 36;
+    gp[6 * (size_t)i + threadIdx.x - 36] = ((s_part[0][u] + s_part[1][u]) + s_part[2][u]) + s_part[3][u];
+  }
+}
+
+// PriorFactorPose3 (gtsam PriorFactor::evaluateError: e = -Local(x, prior), H = I), one lane, in order.
+// mode 0: add information/gradient into Hpp/gp and write the error to err_out[0]
+// mode 1: error only;  mode 2: linearised error 0.5|r + w dp|^2 at OLD poses to err_out[0]
+__global__ void priors_kernel(vus_ba_problem P, const double* __restrict__ poses, const double* __restrict__ dp,
+                              double* __restrict__ Hpp, double* __restrict__ gp, double* __restrict__ err_out,
+                              int mode) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  double e = 0;
+  for (int q = 0; q < P.n_priors; ++q) {
+    const int i = P.prior_pose[q];
+    double xi[6];
+    pose_local(poses + 12 * (size_t)i, P.prior_T + 12 * (size_t)q, xi);
+    for (int k = 0; k < 6; ++k) {
+      const double w = P.prior_w[6 * (size_t)q + k];
+      double r = -xi[k] * w;
+      if (mode == 0) {
+        Hpp[36 * (size_t)i + 7 * k] += w * w;
+        gp[6 * (size_t)i + k] += w * r;
+      }
+      if (mode == 2) r += w * dp[6 * (size_t)i + k];
+      e += 0.5 * r * r;
+    }
+  }
+  err_out[0] = e;
+}
+
+// out[0] = sum of part[0..n) in a fixed order (one workgroup)
+__global__ __launch_bounds__(1024) void reduce_partials_kernel(const double* __restrict__ part, int n,
+                                                               double* __restrict__ out) {
+  __shared__ double s[1024];
+  double acc = 0;
+  for (int k = threadIdx.x; k < n; k += 1024) acc += part[k];
+  s[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = s[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// damped landmark elimination
+__global__ void vinv_kernel(int n_points, double lambda, const double* __restrict__ V, double* __restrict__ Vinv) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_points) return;
+  const double a = V[6 * (size_t)j] + lambda, b = V[6 * (size_t)j + 1], c = V[6 * (size_t)j + 2];
+  const double d = V[6 * (size_t)j + 3] + lambda, e = V[6 * (size_t)j + 4], f = V[6 * (size_t)j + 5] + lambda;
+  const double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  const double id = 1.0 / (a * c00 + b * c01 + c * c02);
+  double* o = Vinv + 6 * (size_t)j;
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id;
+  o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
+}
+
+__global__ void ymul_kernel(vus_ba_problem P, const double* __restrict__ W, const double* __restrict__ Vinv,
+                            double* __restrict__ Y) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= P.n_obs) return;
+  const int j = P.obs_point[P.pobs_lidx[s]];
+  double vi[6];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) vi[k] = Vinv[6 * (size_t)j + k];
+  const double* Ws = W + 18 * (size_t)s;
+  double* Ys = Y + 18 * (size_t)s;
+#pragma unroll
+  for (int rr = 0; rr < 6; ++rr) {
+    const double w0 = Ws[3 * rr], w1 = Ws[3 * rr + 1], w2 = Ws[3 * rr + 2];
+    Ys[3 * rr + 0] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+    Ys[3 * rr + 1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+    Ys[3 * rr + 2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
+  }
+}
+
+// diagonal blocks S_ii = Hpp_i + lambda I (the band was zeroed before)
+__global__ void schur_init_kernel(int n_poses, int band, double lambda, const double* __restrict__ Hpp,
+                                  double* __restrict__ Sband) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= 36 * n_poses) return;
+  const int i = t / 36, e = t - 36 * i;
+  Sband[36 * (size_t)i * (band + 1) + e] = Hpp[t] + ((e % 7 == 0) ? lambda : 0.0);
+}
+
+// One wave per non-zero block (i,k): S_ik -= sum_pairs Y_a W_b^T.
+// 60 lanes = 5 pair slices x 12 strips (row r, three columns); slices are summed in a fixed order.
+__global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, const double* __restrict__ W,
+                                                           const double* __restrict__ Y,
+                                                           double* __restrict__ Sband) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= S.n_blocks) return;
+  const int i = S.blk_i[q], k = S.blk_k[q];
+  const int p0 = S.blk_ptr[q], p1 = S.blk_ptr[q + 1];
+  const int sl = lane / 12, within = lane - 12 * sl;
+  const int r = within >> 1, ch = within & 1;
+  double acc0 = 0, acc1 = 0, acc2 = 0;
+  if (sl < 5) {
+    for (int p = p0 + sl; p < p1; p += 5) {
+      const double* Ya = Y + 18 * (size_t)S.pair_a[p] + 3 * r;
+      const double* Wb = W + 18 * (size_t)S.pair_b[p] + 9 * ch;
+      const double y0 = Ya[0], y1 = Ya[1], y2 = Ya[2];
+      acc0 += y0 * Wb[0] + y1 * Wb[1] + y2 * Wb[2];
+      acc1 += y0 * Wb[3] + y1 * Wb[4] + y2 * Wb[5];
+      acc2 += y0 * Wb[6] + y1 * Wb[7] + y2 * Wb[8];
+    }
+  }
+  double t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+  for (int s = 0; s < 5; ++s) {
+    t0 += __shfl(acc0, within + 12 * s);
+    t1 += __shfl(acc1, within + 12 * s);
+    t2 += __shfl(acc2, within + 12 * s);
+  }
+  if (lane < 12) {
+    double* blk = Sband + 36 * ((size_t)i * (S.band + 1) + (i - k)) + 6 * r + 3 * ch;
+    blk[0] -= t0;
+    blk[1] -= t1;
+    blk[2] -= t2;
+  }
+}
+
+// gs_i = gp_i - sum_{slots of pose i} Y_s gl[point(s)]   (one wave per pose)
+__global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const double* __restrict__ Y,
+                                                       const double* __restrict__ gl,
+                                                       const double* __restrict__ gp, double* __restrict__ gs) {
+  const int i = blockIdx.x;
+  const int lane = threadIdx.x;
+  double acc[6] = {0, 0, 0, 0, 0, 0};
+  for (int s = P.pose_ptr[i] + lane; s < P.pose_ptr[i + 1]; s += 64) {
+    const int j = P.obs_point[P.pobs_lidx[s]];
+    const double g0 = gl[3 * (size_t)j], g1 = gl[3 * (size_t)j + 1], g2 = gl[3 * (size_t)j + 2];
+    const double* Ys = Y + 18 * (size_t)s;
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) acc[rr] += Ys[3 * rr] * g0 + Ys[3 * rr + 1] * g1 + Ys[3 * rr + 2] * g2;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 6; ++rr) acc[rr] = wave_sum(acc[rr]);
+  if (lane < 6) gs[6 * (size_t)i + lane] = gp[6 * (size_t)i + lane] - acc[lane];
+}
+
+// ---------------------------------------------------------------------------------------------
+// block-band Cholesky, right-looking, panels of PB poses (NB = 6 PB scalar columns).
+// Sband entry (i, s) is the 6x6 block (i, i - s), s in [0, band].
+constexpr int PB = 8;
+constexpr int NB = 6 * PB;
+constexpr int LDD = NB + 1;
+
+__device__ __forceinline__ double* blk_ptr(double* Sb, int band, int i, int k) {
+  return Sb + 36 * ((size_t)i * (band + 1) + (i - k));
+}
+
+// Factor the diagonal panel block (lower) in LDS, with the right-hand side riding along as an extra
+// row (so the forward substitution L y = -gs is done by the same row operations).
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
+                                                         double* __restrict__ yv, int* __restrict__ status) {
+  __shared__ double D[(NB + 1) * LDD];
+  const int tid = threadIdx.x;
+  const int pb = min(PB, n_poses - k0);
+  const int nb = 6 * pb;
+  for (int t = tid; t < (nb + 1) * nb; t += 256) {
+    const int R = t / nb, C = t - R * nb;
+    double v = 0.0;
+    if (R == nb) {
+      v = yv[6 * (size_t)k0 + C];
+    } else if (C <= R) {
+      const int ii = R / 6, kk = C / 6;
+      if (ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)];
+    }
+    D[R * LDD + C] = v;
+  }
+  __syncthreads();
+  for (int c = 0; c < nb; ++c) {
+    if (tid == 0) {
+      double d = D[c * LDD + c];
+      if (!(d > 0.0)) {
+        if (status[0] == 0) status[0] = 6 * k0 + c + 1;
+        d = 1.0;
+      }
+      D[c * LDD + c] = sqrt(d);
+    }
+    __syncthreads();
+    const double inv = 1.0 / D[c * LDD + c];
+    for (int R = c + 1 + tid; R <= nb; R += 256) D[R * LDD + c] *= inv;
+    __syncthreads();
+    // trailing update of the panel block and the rhs row
+    const int m = nb - c;  // rows c+1..nb  (m of them), columns c+1..min(R, nb-1)
+    for (int t = tid; t < m * m; t += 256) {
+      const int R = c + 1 + t / m, C = c + 1 + t % m;
+      if (C <= R && C < nb) D[R * LDD + C] -= D[R * LDD + c] * D[C * LDD + c];
+    }
+    __syncthreads();
+  }
+  for (int t = tid; t < (nb + 1) * nb; t += 256) {
+    const int R = t / nb, C = t - R * nb;
+    if (R == nb) {
+      yv[6 * (size_t)k0 + C] = D[R * LDD + C];
+    } else if (C <= R) {
+      const int ii = R / 6, kk = C / 6;
+      if (ii - kk <= band) blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)] = D[R * LDD + C];
+    } else if (R / 6 == C / 6) {
+      // keep the diagonal 6x6 blocks' upper parts harmless (zero): only the lower factor is used
+      blk_ptr(Sb, band, k0 + R / 6, k0 + C / 6)[6 * (R % 6) + (C % 6)] = 0.0;
+    }
+  }
+}
+
+// Rows below the panel: L_row,panel = A_row,panel * L_D^-T, one scalar row per thread (row staged in LDS).
+constexpr int TRSM_T = 128;
+__global__ __launch_bounds__(TRSM_T) void chol_trsm_kernel(double* __restrict__ Sb, int n_poses, int band, int k0) {
+  __shared__ double L[NB * LDD];
+  __shared__ double X[TRSM_T * LDD];
+  const int tid = threadIdx.x;
+  const int pb = min(PB, n_poses - k0);
+  const int nb = 6 * pb;
+  for (int t = tid; t < nb * nb; t += TRSM_T) {
+    const int R = t / nb, C = t - R * nb;
+    double v = 0.0;
+    const int ii = R / 6, kk = C / 6;
+    if (C <= R && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)];
+    L[R * LDD + C] = v;
+  }
+  const int i_first = k0 + pb;
+  const int i_last = min(n_poses - 1, k0 + pb - 1 + band);
+  const int row = blockIdx.x * TRSM_T + tid;  // scalar row index inside the window
+  const int i = i_first + row / 6, rr = row % 6;
+  const bool active = i <= i_last;
+  int kk_min = 0;
+  double* x = X + tid * LDD;
+  if (active) {
+    kk_min = max(0, i - band - k0);  // first panel pose inside this row's band
+    for (int kk = kk_min; kk < pb; ++kk) {
+      const double* b = blk_ptr(Sb, band, i, k0 + kk) + 6 * rr;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) x[6 * kk + c] = b[c];
+    }
+  }
+  __syncthreads();
+  if (active) {
+    for (int c = 6 * kk_min; c < nb; ++c) {
+      double t = x[c];
+      for (int k = 6 * kk_min; k < c; ++k) t -= x[k] * L[c * LDD + k];
+      x[c] = t / L[c * LDD + c];
+    }
+    for (int kk = kk_min; kk < pb; ++kk) {
+      double* b = blk_ptr(Sb, band, i, k0 + kk) + 6 * rr;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) b[c] = x[6 * kk + c];
+    }
+  }
+}
+
+// Trailing update of one pose row i of the window: A_ij -= L_i,panel L_j,panel^T for j in [max(first, i-band), i],
+// and the rhs rides along: y_i -= L_i,panel y_panel.
+__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
+                                                          double* __restrict__ yv) {
+  __shared__ double Li[6 * NB];
+  const int tid = threadIdx.x;
+  const int pb = min(PB, n_poses - k0);
+  const int nb = 6 * pb;
+  const int i_first = k0 + pb;
+  const int i = i_first + blockIdx.x;
+  const int kk_min = max(0, i - band - k0);
+  for (int t = tid; t < 6 * nb; t += 256) {
+    const int rr = t / nb, c = t - rr * nb;
+    const int kk = c / 6;
+    Li[rr * NB + c] = kk >= kk_min ? blk_ptr(Sb, band, i, k0 + kk)[6 * rr + (c % 6)] : 0.0;
+  }
+  __syncthreads();
+  const int j_first = max(i_first, i - band);
+  const int n_tasks = (i - j_first + 1) * 36;
+  for (int t = tid; t < n_tasks; t += 256) {
+    const int j = j_first + t / 36, e = t % 36;
+    const int rr = e / 6, c = e - 6 * rr;
+    double acc = 0.0;
+    for (int kk = kk_min; kk < pb; ++kk) {  // kk_min(i) >= kk_min(j): both factors exist
+      const double* lj = blk_ptr(Sb, band, j, k0 + kk) + 6 * c;
+      const double* li = Li + rr * NB + 6 * kk;
+#pragma unroll
+      for (int u = 0; u < 6; ++u) acc += li[u] * lj[u];
+    }
+    blk_ptr(Sb, band, i, j)[e] -= acc;
+  }
+  if (tid < 6) {
+    double acc = 0.0;
+    for (int c = 6 * kk_min; c < nb; ++c) acc += Li[tid * NB + c] * yv[6 * (size_t)k0 + c];
+    yv[6 * (size_t)i + tid] -= acc;
+  }
+}
+
+// x = L^-T y in place (yv), right-looking from the last pose to the first, one workgroup.
+// The working vector lives in LDS when it fits (n <= 12288 scalars), else in global memory.
+constexpr int BS_THREADS = 1024;
+constexpr int BS_LDS_N = 12288;
+__global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(const double* __restrict__ Sb, int n_poses,
+                                                                    int band, double* __restrict__ yv) {
+  extern __shared__ double s_y[];
+  const int tid = threadIdx.x;
+  const int n = 6 * n_poses;
+  const bool in_lds = n <= BS_LDS_N;
+  double* y = in_lds ? s_y : yv;
+  if (in_lds) {
+    for (int t = tid; t < n; t += BS_THREADS) s_y[t] = yv[t];
+  }
+  __syncthreads();
+  for (int k = n_poses - 1; k >= 0; --k) {
+    const double* Lkk = Sb + 36 * (size_t)k * (band + 1);
+    if (tid == 0) {
+      double x[6];
+#pragma unroll
+      for (int c = 5; c >= 0; --c) {
+        double t = y[6 * k + c];
+#pragma unroll
+        for (int r = c + 1; r < 6; ++r) t -= Lkk[6 * r + c] * x[r];
+        x[c] = t / Lkk[7 * c];
+      }
+#pragma unroll
+      for (int c = 0; c < 6; ++c) y[6 * k + c] = x[c];
+    }
+    __syncthreads();
+    const int nrows = min(band, k);
+    for (int t = tid; t < 6 * nrows; t += BS_THREADS) {
+      const int i = k - 1 - t / 6, c = t % 6;
+      const double* Lki = Sb + 36 * ((size_t)k * (band + 1) + (k - i));
+      double acc = 0.0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) acc += Lki[6 * r + c] * y[6 * k + r];
+      y[6 * i + c] -= acc;
+    }
+    __syncthreads();
+  }
+  if (in_lds) {
+    for (int t = tid; t < n; t += BS_THREADS) yv[t] = s_y[t];
+  }
+}
+
+__global__ void negate_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) dst[t] = -src[t];
+}
+
+// ---------------------------------------------------------------------------------------------
+// back-substitution, retraction, error evaluation
+__global__ __launch_bounds__(256) void backsub_kernel(vus_ba_problem P, const double* __restrict__ W,
+                                                      const double* __restrict__ Vinv,
+                                                      const double* __restrict__ gl, const double* __restrict__ dp,
+                                                      double* __restrict__ dl) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= P.n_points) return;
+  double t[3] = {0, 0, 0};
+  for (int a = P.point_ptr[j] + lane; a < P.point_ptr[j + 1]; a += 64) {
+    const double* Wa = W + 18 * (size_t)P.obs_ppos[a];
+    const double* d = dp + 6 * (size_t)P.obs_pose[a];
+#pragma unroll
+    for (int rr = 0; rr < 6; ++rr) {
+      const double dr = d[rr];
+      t[0] += Wa[3 * rr] * dr;
+      t[1] += Wa[3 * rr + 1] * dr;
+      t[2] += Wa[3 * rr + 2] * dr;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) t[c] = wave_sum(t[c]);
+  if (lane == 0) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] += gl[3 * (size_t)j + c];
+    const double* vi = Vinv + 6 * (size_t)j;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+      dl[3 * (size_t)j + c] = -(sym3(vi, c, 0) * t[0] + sym3(vi, c, 1) * t[1] + sym3(vi, c, 2) * t[2]);
+  }
+}
+
+__global__ void retract_kernel(int n_poses, int n_points, const double* __restrict__ poses,
+                               const double* __restrict__ points, const double* __restrict__ dp,
+                               const double* __restrict__ dl, double* __restrict__ new_poses,
+                               double* __restrict__ new_points) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_poses) {
+    double T[12], xi[6], out[12];
+    load12(poses + 12 * (size_t)t, T);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xi[k] = dp[6 * (size_t)t + k];
+    pose_retract(T, xi, out);
+#pragma unroll
+    for (int k = 0; k < 12; ++k) new_poses[12 * (size_t)t + k] = out[k];
+  }
+  for (int k = t; k < 3 * n_points; k += gridDim.x * blockDim.x) new_points[k] = points[k] + dl[k];
+}
+
+// per point: part_lin[j] = 0.5 sum |r + H1 dp + H2 dl|^2 at the old values,
+//            part_new[j] = 0.5 sum |r|^2 at the new values
+template <bool WITH_LIN>
+__global__ __launch_bounds__(256) void eval_points_kernel(vus_ba_problem P, const double* __restrict__ poses,
+                                                          const double* __restrict__ points,
+                                                          const double* __restrict__ dp, const double* __restrict__ dl,
+                                                          const double* __restrict__ new_poses,
+                                                          const double* __restrict__ new_points,
+                                                          double* __restrict__ part_lin, double* __restrict__ part_new) {
+  const int lane = threadIdx.x & 63;
+  const int j = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (j >= P.n_points) return;
+  const Calib K = load_calib(P.K, P.inv_sigma);
+  const double pn[3] = {new_points[3 * (size_t)j], new_points[3 * (size_t)j + 1], new_points[3 * (size_t)j + 2]};
+  double po[3] = {0, 0, 0}, d_l[3] = {0, 0, 0};
+  if (WITH_LIN) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      po[c] = points[3 * (size_t)j + c];
+      d_l[c] = dl[3 * (size_t)j + c];
+    }
+  }
+  double e_lin = 0, e_new = 0;
+  for (int a = P.point_ptr[j] + lane; a < P.point_ptr[j + 1]; a += 64) {
+    const int i = P.obs_pose[a];
+    const double m[3] = {P.meas[3 * (size_t)a], P.meas[3 * (size_t)a + 1], P.meas[3 * (size_t)a + 2]};
+    double T[12], r[3];
+    load12(new_poses + 12 * (size_t)i, T);
+    stereo_factor<false, false>(T, pn, m, K, r, nullptr, nullptr);
+    e_new += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
+    if (WITH_LIN) {
+      double H1[18], H2[9];
+      load12(poses + 12 * (size_t)i, T);
+      stereo_factor<true, true>(T, po, m, K, r, H1, H2);
+      const double* d = dp + 6 * (size_t)i;
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {
+        double t = r[rr];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) t += H1[6 * rr + c] * d[c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t += H2[3 * rr + c] * d_l[c];
+        e_lin += 0.5 * t * t;
+      }
+    }
+  }
+  e_new = wave_sum(e_new);
+  if (WITH_LIN) e_lin = wave_sum(e_lin);
+  if (lane == 0) {
+    part_new[j] = e_new;
+    if (WITH_LIN) part_lin[j] = e_lin;
+  }
+}
+
+int check_problem(const vus_ba_problem* P) {
+  VUS_REQUIRE(P != nullptr, "problem is null");
+  VUS_REQUIRE(P->n_poses >= 1 && P->n_points >= 0 && P->n_obs >= 0 && P->n_priors >= 0,
+              "bad sizes: poses=%d points=%d obs=%d priors=%d", P->n_poses, P->n_points, P->n_obs, P->n_priors);
+  VUS_REQUIRE(P->K != nullptr, "K is null");
+  VUS_REQUIRE(P->inv_sigma > 0.0, "inv_sigma=%g", P->inv_sigma);
+  if (P->n_obs > 0)
+    VUS_REQUIRE(P->meas && P->obs_pose && P->obs_point && P->point_ptr && P->obs_ppos && P->pose_ptr && P->pobs_lidx,
+                "observation arrays are null");
+  if (P->n_priors > 0) VUS_REQUIRE(P->prior_pose && P->prior_T && P->prior_w, "prior arrays are null");
+  return VUS_OK;
+}
+
+inline int cdiv(long long a, int b) { return (int)((a + b - 1) / b); }
+
+}  // namespace
+
+extern "C" long long vus_ba_work_doubles(const vus_ba_problem* P) {
+  if (!P) return 0;
+  return 2ll * ((long long)P->n_points + 1) + 8;
+}
+
+extern "C" int vus_ba_error(const vus_ba_problem* P, const double* poses, const double* points, double* err,
+                            double* work, void* stream) {
+  if (int rc = check_problem(P)) return rc;
+  VUS_REQUIRE(poses && points && err && work, "null buffer");
+  hipStream_t st = vus::as_stream(stream);
+  const int nL = P->n_points;
+  if (nL > 0)
+    eval_points_kernel<false><<<cdiv(nL, 4), 256, 0, st>>>(*P, nullptr, nullptr, nullptr, nullptr, poses, points,
+                                                          nullptr, work);
+  priors_kernel<<<1, 64, 0, st>>>(*P, poses, nullptr, nullptr, nullptr, work + nL, 1);
+  reduce_partials_kernel<<<1, 1024, 0, st>>>(work, nL + 1, err);
+  VUS_CHECK_LAUNCH("ba_error");
+  return VUS_OK;
+}
+
+extern "C" int vus_ba_linearize(const vus_ba_problem* P, const double* poses, const double* points, double* W,
+                                double* V, double* gl, double* Hpp, double* gp, double* err, double* work,
+                                void* stream) {
+  if (int rc = check_problem(P)) return rc;
+  VUS_REQUIRE(poses && points && W && V && gl && Hpp && gp && err && work, "null buffer");
+  hipStream_t st = vus::as_stream(stream);
+  const int nL = P->n_points;
+  if (nL > 0) lin_points_kernel<<<cdiv(nL, 4), 256, 0, st>>>(*P, poses, points, W, V, gl, work);
+  lin_poses_kernel<<<P->n_poses, 256, 0, st>>>(*P, poses, points, Hpp, gp);
+  priors_kernel<<<1, 64, 0, st>>>(*P, poses, nullptr, Hpp, gp, work + nL, 0);
+  reduce_partials_kernel<<<1, 1024, 0, st>>>(work, nL + 1, err);
+  VUS_CHECK_LAUNCH("ba_linearize");
+  return VUS_OK;
+}
+
+extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lambda, const double* W,
+                            const double* V, const double* gl, const double* Hpp, const double* gp, double* Vinv,
+                            double* Y, double* Sband, double* gs, void* stream) {
+  if (int rc = check_problem(P)) return rc;
+  VUS_REQUIRE(S != nullptr, "structure is null");
+  VUS_REQUIRE(S->band >= 0 && S->band < P->n_poses + 1 && S->n_blocks >= 0 && S->n_pairs >= 0,
+              "bad structure: band=%d blocks=%d pairs=%d", S->band, S->n_blocks, S->n_pairs);
+  VUS_REQUIRE(W && V && gl && Hpp && gp && Vinv && Y && Sband && gs, "null buffer");
+  if (S->n_blocks > 0) VUS_REQUIRE(S->blk_ptr && S->blk_i && S->blk_k && S->pair_a && S->pair_b, "structure arrays are null");
+  VUS_REQUIRE(lambda >= 0.0, "lambda=%g", lambda);
+  hipStream_t st = vus::as_stream(stream);
+  const int nP = P->n_poses, nL = P->n_points, nO = P->n_obs;
+  VUS_CHECK_HIP(hipMemsetAsync(Sband, 0, sizeof(double) * 36 * (size_t)nP * (S->band + 1), st));
+  if (nL > 0) vinv_kernel<<<cdiv(nL, 256), 256, 0, st>>>(nL, lambda, V, Vinv);
+  if (nO > 0) ymul_kernel<<<cdiv(nO, 256), 256, 0, st>>>(*P, W, Vinv, Y);
+  schur_init_kernel<<<cdiv(36ll * nP, 256), 256, 0, st>>>(nP, S->band, lambda, Hpp, Sband);
+  if (S->n_blocks > 0) schur_blocks_kernel<<<cdiv(S->n_blocks, 4), 256, 0, st>>>(*S, W, Y, Sband);
+  schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, Y, gl, gp, gs);
+  VUS_CHECK_LAUNCH("ba_schur");
+  return VUS_OK;
+}
+
+extern "C" int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, double* dp, int* status,
+                                 void* stream) {
+  VUS_REQUIRE(Sband && gs && dp && status, "null buffer");
+  VUS_REQUIRE(n_poses >= 1 && band >= 0, "n_poses=%d band=%d", n_poses, band);
+  hipStream_t st = vus::as_stream(stream);
+  const int n = 6 * n_poses;
+  VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+  negate_copy_kernel<<<cdiv(n, 256), 256, 0, st>>>(gs, dp, n);
+  for (int k0 = 0; k0 < n_poses; k0 += PB) {
+    chol_panel_kernel<<<1, 256, 0, st>>>(Sband, n_poses, band, k0, dp, status);
+    const int pb = n_poses - k0 < PB ? n_poses - k0 : PB;
+    const int i_first = k0 + pb;
+    int i_last = k0 + pb - 1 + band;
+    if (i_last > n_poses - 1) i_last = n_poses - 1;
+    const int rows = i_last - i_first + 1;
+    if (rows > 0) {
+      chol_trsm_kernel<<<cdiv(6ll * rows, TRSM_T), TRSM_T, 0, st>>>(Sband, n_poses, band, k0);
+      chol_update_kernel<<<rows, 256, 0, st>>>(Sband, n_poses, band, k0, dp);
+    }
+  }
+  const size_t lds = n <= BS_LDS_N ? sizeof(double) * (size_t)n : 0;
+  if (lds > 48 * 1024)  // more than the default dynamic-LDS allowance: gfx950 has 160 KiB per workgroup
+    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  chol_backsolve_kernel<<<1, BS_THREADS, lds, st>>>(Sband, n_poses, band, dp);
+  VUS_CHECK_LAUNCH("ba_band_solve");
+  return VUS_OK;
+}
+
+extern "C" int vus_ba_backsub(const vus_ba_problem* P, const double* W, const double* Vinv, const double* gl,
+                              const double* dp, double* dl, void* stream) {
+  if (int rc = check_problem(P)) return rc;
+  VUS_REQUIRE(W && Vinv && gl && dp && dl, "null buffer");
+  if (P->n_points > 0)
+    backsub_kernel<<<cdiv(P->n_points, 4), 256, 0, vus::as_stream(stream)>>>(*P, W, Vinv, gl, dp, dl);
+  VUS_CHECK_LAUNCH("ba_backsub");
+  return VUS_OK;
+}
+
+extern "C" int vus_ba_eval_step(const vus_ba_problem* P, const double* poses, const double* points, const double* dp,
+                                const double* dl, double* new_poses, double* new_points, double* out, double* work,
+                                void* stream) {
+  if (int rc = check_problem(P)) return rc;
+  VUS_REQUIRE(poses && points && dp && dl && new_poses && new_points && out && work, "null buffer");
+  hipStream_t st = vus::as_stream(stream);
+  const int nP = P->n_poses, nL = P->n_points;
+  retract_kernel<<<cdiv(nP > nL ? nP : (nL < 65536 ? nL : 65536), 256) + 1, 256, 0, st>>>(nP, nL, poses, points, dp, dl,
+                                                                                           new_poses, new_points);
+  double* part_lin = work;
+  double* part_new = work + (nL + 1);
+  if (nL > 0)
+    eval_points_kernel<true><<<cdiv(nL, 4), 256, 0, st>>>(*P, poses, points, dp, dl, new_poses, new_points, part_lin,
+                                                         part_new);
+  priors_kernel<<<1, 64, 0, st>>>(*P, poses, dp, nullptr, nullptr, part_lin + nL, 2);
+  priors_kernel<<<1, 64, 0, st>>>(*P, new_poses, nullptr, nullptr, nullptr, part_new + nL, 1);
+  reduce_partials_kernel<<<1, 1024, 0, st>>>(part_lin, nL + 1, out);
+  reduce_partials_kernel<<<1, 1024, 0, st>>>(part_new, nL + 1, out + 1);
+  VUS_CHECK_LAUNCH("ba_eval_step");
+  return VUS_OK;
+}
