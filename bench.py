@@ -177,12 +177,11 @@ def main():
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_frames, 0)
-        if not a.no_ba:
-            try:
-                from visual_underwater_slam_amd import ba_bench
-                out["ba"] = ba_bench.run(device)
-            except ImportError:
-                pass
+        if not a.no_ba and world == 1:
+            from visual_underwater_slam_amd import ba_bench
+            del fe, images
+            torch.cuda.empty_cache()
+            out["ba"] = ba_bench.run(device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

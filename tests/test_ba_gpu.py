@@ -159,3 +159,43 @@ def test_cheirality_factor_matches_oracle(gpu, oracle):
     assert np.isclose(float(sv.scal[0]), lin["err"], rtol=1e-12)
     assert relerr(sv.V.cpu().numpy(), lin["V"]) < 1e-11 and np.all(lin["V"][3] == 0)
     assert np.array_equal(sv.V.cpu().numpy()[3], np.zeros(6))
+
+
+def test_gtsam_shaped_optimize_is_a_drop_in(gpu, oracle):
+    """batch.py:336-337 against our module: object-by-object graph and the bulk block give the same
+    optimum as the CPU oracle; inputs stay untouched; read-back works like batch.py:57-68."""
+    import visual_underwater_slam_amd.gtsam as gtsam
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import X, L, V
+    from test_gtsam_boundary import mini_batch_create
+    seq = synth.ba_sequence(50, 500, 100)
+    graph, initial = mini_batch_create(seq)
+    before = initial.atPose3(X(7)).flat12().copy()
+    opt = gtsam.LevenbergMarquardtOptimizer(graph, initial, gtsam.LevenbergMarquardtParams())
+    results = opt.optimize()
+    assert np.array_equal(initial.atPose3(X(7)).flat12(), before)            # inputs untouched
+    nL = len(seq["points_gt"])
+    pk = ba_pack.pack_observations(torch.from_numpy(seq["obs_pose"]), torch.from_numpy(seq["obs_point"]),
+                                   torch.from_numpy(seq["meas"]), 50, nL)
+    st = ba_pack.build_structure(pk)
+    P = oracle.BAProblem(pk, seq["K"], seq["sigma"], (np.array([0], np.int32), seq["poses_init"][:1], seq["prior_sigmas"][None]))
+    oposes, opoints, orep = oracle.ba_lm_optimize(P, st["band"], seq["poses_init"], seq["points_init"])
+    got = np.stack([results.atPose3(X(i)).flat12() for i in range(50)])
+    assert relerr(got, oposes) < 1e-6
+    assert relerr(np.stack([results.atPoint3(L(j)) for j in range(nL)]), opoints) < 1e-6
+    assert opt.iterations() == orep["iterations"] and np.isclose(opt.error(), orep["final_error"], rtol=1e-8)
+    assert results.atVector(V(0)).tolist() == [0.0, 0.0, 0.0]                # prior-only velocity stays at its prior
+    assert np.isclose(graph.error(initial), orep["initial_error"], rtol=1e-10)
+    # constr3DPoints of batch.py:57-68
+    i, pts = 0, []
+    while results.exists(X(i)):
+        p = results.atPose3(X(i)); pts.append([p.x(), p.y(), p.z()]); i += 1
+    assert i == 50 and np.abs(np.array(pts) - seq["poses_gt"][:, 9:]).max() < 0.05
+    # bulk emission gives the same answer
+    g2 = gtsam.NonlinearFactorGraph()
+    g2.add(gtsam.PriorFactorPose3(X(0), gtsam.Pose3.from_flat12(seq["poses_init"][0]),
+                                  gtsam.noiseModel.Diagonal.Sigmas(seq["prior_sigmas"])))
+    g2.push_back(gtsam.StereoFactorBlock(seq["meas"], gtsam.noiseModel.Isotropic.Sigma(3, 10.0),
+                                         [X(int(i)) for i in seq["obs_pose"]], [L(int(j)) for j in seq["obs_point"]],
+                                         gtsam.Cal3_S2Stereo(*seq["K"])))
+    r2 = gtsam.LevenbergMarquardtOptimizer(g2, initial, gtsam.LevenbergMarquardtParams()).optimize()
+    assert relerr(np.stack([r2.atPose3(X(i)).flat12() for i in range(50)]), got) < 1e-12

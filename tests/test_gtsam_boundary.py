@@ -1,0 +1,184 @@
+"""The gtsam-shaped boundary: every symbol /root/reference/batch.py uses,
+with the same argument meaning and error behaviour.  CPU-only: host logic and packing."""
+import os
+
+import numpy as np
+import pytest
+
+import visual_underwater_slam_amd.gtsam as gtsam
+from visual_underwater_slam_amd.gtsam import (ISAM2, BetweenFactorConstantBias, Cal3_S2, ImuFactor,  # noqa: F401
+                                               NonlinearFactorGraph, Point3, Pose3, PriorFactorConstantBias,
+                                               PriorFactorPose3, PriorFactorVector, Rot3, Values,
+                                               PriorFactorPoint3, NavState, Cal3_S2Stereo, StereoPoint2,
+                                               GenericStereoFactor3D)                  # batch.py:20-25
+from visual_underwater_slam_amd.gtsam.symbol_shorthand import B, V, X, L               # batch.py:26
+from visual_underwater_slam_amd.gtsam.optimizer import _pack_graph
+from visual_underwater_slam_amd import synth
+
+
+def test_symbol_keys():
+    assert X(0) == ord("x") << 56 and L(7) == (ord("l") << 56) | 7
+    assert gtsam.symbol_shorthand.symbolChr(V(3)) == "v" and gtsam.symbol_shorthand.symbolIndex(B(9)) == 9
+    assert len({X(1), V(1), B(1), L(1)}) == 4
+
+
+def test_rot3_pose3_basics():
+    r = Rot3.Quaternion(1, 0, 0, 0)
+    assert np.allclose(r.matrix(), np.eye(3))
+    q = np.array([0.9, 0.1, -0.3, 0.2]); q /= np.linalg.norm(q)
+    R = Rot3.Quaternion(*q).matrix()
+    assert np.allclose(R @ R.T, np.eye(3)) and np.isclose(np.linalg.det(R), 1.0)
+    # scipy convention check (x,y,z,w there)
+    from scipy.spatial.transform import Rotation
+    assert np.allclose(R, Rotation.from_quat([q[1], q[2], q[3], q[0]]).as_matrix())
+    assert np.allclose(Rot3.Rodrigues(0, 0, 0).matrix(), np.eye(3))
+    assert np.allclose(Rot3.Rodrigues(0, 0, np.pi / 2).matrix(), [[0, -1, 0], [1, 0, 0], [0, 0, 1]], atol=1e-15)
+    p = Pose3(Rot3.Quaternion(*q), Point3(1, 2, 3))
+    assert (p.x(), p.y(), p.z()) == (1.0, 2.0, 3.0)
+    assert np.allclose(p.rotation().matrix(), R)
+    assert Pose3().equals(p.compose(p.inverse()), 1e-12)
+    assert np.allclose(p.transformTo(p.transformFrom([4, 5, 6])), [4, 5, 6])
+    assert np.allclose(Pose3.from_flat12(p.flat12()).matrix(), p.matrix())
+    assert Point3().tolist() == [0, 0, 0] and Point3(1, 2, 3).reshape(3, 1).shape == (3, 1)   # batch.py:84,166
+
+
+def test_values_semantics_and_errors():
+    v = Values()
+    v.insert(B(0), gtsam.imuBias.ConstantBias())                     # batch.py:274
+    v.insert(X(0), Pose3())                                          # :283
+    v.insert(V(0), np.array([0.0, 0, 0]))                            # :284
+    v.insert(L(5), np.array([1.0, 2.0, 3.0]))                        # :298 (numpy 3-vector)
+    assert v.exists(X(0)) and not v.exists(X(1)) and not v.exists(0)  # :60,:66,:297
+    assert isinstance(v.atPose3(X(0)), Pose3) and v.atVector(V(0)).tolist() == [0, 0, 0]
+    assert v.atPoint3(L(5)).tolist() == [1, 2, 3] and v.size() == 4
+    with pytest.raises(RuntimeError, match="already exists"):
+        v.insert(X(0), Pose3())
+    with pytest.raises(RuntimeError, match="does not exist"):
+        v.atPose3(X(3))
+    with pytest.raises(RuntimeError):
+        v.atPose3(V(0))
+    v2 = Values(v)
+    v2.update(L(5), np.array([9.0, 9, 9]))
+    assert v.atPoint3(L(5)).tolist() == [1, 2, 3]                    # copies are independent
+
+
+def test_noise_models():
+    d = gtsam.noiseModel.Diagonal.Sigmas(np.array([0.1, 0.1, 0.1, 0.3, 0.3, 0.3]))    # batch.py:95
+    assert d.dim() == 6 and not d.is_isotropic()
+    i = gtsam.noiseModel.Isotropic.Sigma(3, 10)                                       # :118
+    assert i.sigmas().tolist() == [10, 10, 10] and i.is_isotropic()
+    assert np.allclose(gtsam.noiseModel.Isotropic.Variance(6, 0.1).sigmas(), np.sqrt(0.1))   # :189
+    with pytest.raises(RuntimeError):
+        gtsam.noiseModel.Isotropic.Sigma(3, 0.0)
+
+
+def mini_batch_create(seq, with_imu=False):
+    """The stereo slice of AUV_ISAM.batch_create (batch.py:270-305), written against our module the
+    way the reference writes it against gtsam."""
+    K = Cal3_S2Stereo(*seq["K"])                                                      # :115
+    landmark_noise = gtsam.noiseModel.Isotropic.Sigma(3, seq["sigma"])                # :118
+    pose_noise = gtsam.noiseModel.Diagonal.Sigmas(seq["prior_sigmas"])                # :95
+    vel_noise = gtsam.noiseModel.Isotropic.Sigma(3, 0.1)                              # :96
+    initial_estimate, graph = Values(), NonlinearFactorGraph()                        # :271-272
+    initial_estimate.insert(B(0), gtsam.imuBias.ConstantBias())                       # :274
+    by_pose = {}
+    for a in range(len(seq["obs_pose"])):
+        by_pose.setdefault(int(seq["obs_pose"][a]), []).append(a)
+    pim = gtsam.PreintegratedImuMeasurements(gtsam.PreintegrationParams.MakeSharedU(9.81))
+    for i in range(len(seq["poses_init"])):
+        pose = Pose3.from_flat12(seq["poses_init"][i])
+        velocity = np.array([0.0, 0.0, 0.0])
+        if i == 0:
+            graph.add(PriorFactorPose3(X(0), pose, pose_noise))                       # :281
+            graph.add(PriorFactorVector(V(0), velocity, vel_noise))                   # :282
+        initial_estimate.insert(X(i), pose)                                          # :283/:287
+        initial_estimate.insert(V(i), velocity)                                      # :284/:288
+        if i > 0 and with_imu:
+            pim.integrateMeasurement(np.zeros(3), np.zeros(3), 0.005)                 # :290
+            graph.push_back(ImuFactor(X(i - 1), V(i - 1), X(i), V(i), B(0), pim))     # :291
+            pim.resetIntegration()                                                    # :293
+        for a in by_pose.get(i, []):                                                  # :296 (all keyframes: see DESIGN.md)
+            lid = int(seq["obs_point"][a])
+            if not initial_estimate.exists(L(lid)):                                   # :297
+                initial_estimate.insert(L(lid), seq["points_init"][lid])              # :298
+            graph.push_back(GenericStereoFactor3D(StereoPoint2(*seq["meas"][a]), landmark_noise,
+                                                  X(i), L(lid), K))                   # :300-305
+    return graph, initial_estimate
+
+
+def test_pack_graph_matches_sequence_arrays():
+    seq = synth.ba_sequence(12, 60, 30)
+    graph, initial = mini_batch_create(seq)
+    assert graph.size() == len(seq["obs_pose"]) + 2
+    pg = _pack_graph(graph, initial)
+    assert np.array_equal(pg["pose_keys"], [X(i) for i in range(12)])
+    assert np.array_equal(pg["lm_keys"], [L(j) for j in range(len(seq["points_gt"]))])
+    order = np.lexsort((pg["pose_idx"], pg["lm_idx"]))
+    assert np.array_equal(pg["pose_idx"][order], seq["obs_pose"]) and np.array_equal(pg["lm_idx"][order], seq["obs_point"])
+    assert np.array_equal(pg["meas"][order], seq["meas"])
+    assert np.array_equal(pg["poses"], seq["poses_init"]) and np.array_equal(pg["points"], seq["points_init"])
+    assert pg["sigma"] == 10.0 and np.array_equal(pg["K"], seq["K"])
+    assert pg["prior_idx"].tolist() == [0] and np.array_equal(pg["prior_T"][0], seq["poses_init"][0])
+    assert pg["aux"].keys == [V(0)]
+    # bulk emission (extension) packs identically
+    g2 = NonlinearFactorGraph()
+    g2.add(PriorFactorPose3(X(0), Pose3.from_flat12(seq["poses_init"][0]), gtsam.noiseModel.Diagonal.Sigmas(seq["prior_sigmas"])))
+    g2.push_back(gtsam.StereoFactorBlock(seq["meas"], gtsam.noiseModel.Isotropic.Sigma(3, 10.0),
+                                         [X(int(i)) for i in seq["obs_pose"]], [L(int(j)) for j in seq["obs_point"]],
+                                         Cal3_S2Stereo(*seq["K"])))
+    pg2 = _pack_graph(g2, initial)
+    assert np.array_equal(pg2["pose_idx"], seq["obs_pose"]) and np.array_equal(pg2["meas"], seq["meas"])
+    assert g2.nrFactors() == len(seq["obs_pose"]) + 1
+
+
+def test_unsupported_factors_fail_loudly_at_optimize_time():
+    seq = synth.ba_sequence(6, 30, 10)
+    graph, initial = mini_batch_create(seq, with_imu=True)             # constructing and adding is fine...
+    with pytest.raises(NotImplementedError, match="ImuFactor"):
+        _pack_graph(graph, initial)                                   # ...solving is refused, loudly
+    g = NonlinearFactorGraph()
+    g.push_back(gtsam.CustomFactor(gtsam.noiseModel.Isotropic.Sigma(3, 0.1), [V(1), X(1)], lambda *a: None))
+    with pytest.raises(NotImplementedError, match="CustomFactor"):
+        _pack_graph(g, initial)
+    # mixed noise models / missing variables
+    g = NonlinearFactorGraph()
+    K = Cal3_S2Stereo(*seq["K"])
+    g.push_back(GenericStereoFactor3D(StereoPoint2(1, 2, 3), gtsam.noiseModel.Isotropic.Sigma(3, 10), X(0), L(0), K))
+    g.push_back(GenericStereoFactor3D(StereoPoint2(1, 2, 3), gtsam.noiseModel.Isotropic.Sigma(3, 5), X(1), L(0), K))
+    with pytest.raises(NotImplementedError, match="share one noise model"):
+        _pack_graph(g, initial)
+    g = NonlinearFactorGraph()
+    g.push_back(GenericStereoFactor3D(StereoPoint2(1, 2, 3), gtsam.noiseModel.Isotropic.Sigma(3, 10), X(0), L(10**6), K))
+    with pytest.raises(RuntimeError, match="does not exist"):
+        _pack_graph(g, initial)
+    with pytest.raises(NotImplementedError):
+        ISAM2().update()
+
+
+def test_save_graph_writes_dot(tmp_path):
+    seq = synth.ba_sequence(4, 20, 8)
+    graph, initial = mini_batch_create(seq)
+    path = os.path.join(tmp_path, "graph.dot")
+    graph.saveGraph(path)                                             # batch.py:338
+    txt = open(path).read()
+    assert txt.startswith("graph {") and 'label="x0"' in txt and txt.count("shape=point") == graph.size()
+
+
+def test_lm_params_defaults_and_setters():
+    p = gtsam.LevenbergMarquardtParams()
+    assert (p.getlambdaInitial(), p.getlambdaFactor(), p.getlambdaUpperBound(), p.getlambdaLowerBound()) == (1e-5, 10.0, 1e5, 0.0)
+    assert (p.getMaxIterations(), p.getRelativeErrorTol(), p.getAbsoluteErrorTol(), p.getErrorTol()) == (100, 1e-5, 1e-5, 0.0)
+    assert p.minModelFidelity == 1e-3 and p.getDiagonalDamping() is False
+    p.setMaxIterations(7); p.setlambdaInitial(1.0)
+    lm = p._to_lm()
+    assert lm.maxIterations == 7 and lm.lambdaInitial == 1.0
+
+
+def test_product_needs_gpu_no_cpu_fallback():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    seq = synth.ba_sequence(4, 20, 8)
+    graph, initial = mini_batch_create(seq)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gtsam.LevenbergMarquardtOptimizer(graph, initial, gtsam.LevenbergMarquardtParams()).optimize()

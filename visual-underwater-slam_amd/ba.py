@@ -173,22 +173,22 @@ class StereoBASolver:
 
     # -- Levenberg-Marquardt ----------------------------------------------------------------------
     def optimize(self, poses: torch.Tensor, points: torch.Tensor, params: Optional[LMParams] = None,
-                 extra_error=None):
+                 aux=None):
         """poses [nP,12], points [nL,3] float64 on the GPU; returns optimised copies and an LMReport.
-        `extra_error` is a constant added to every error (factors the solver does not touch)."""
+        `aux` (optional) carries host-side variables that decouple from the camera system (vector
+        variables with only a prior factor): .error(), .try_lambda(lam) -> (lin, new), .accept()."""
         prm = params or LMParams()
         if prm.diagonalDamping:
             raise NotImplementedError("diagonalDamping=True is not implemented (gtsam default is False)")
         if not prm.useFixedLambdaFactor:
             raise NotImplementedError("useFixedLambdaFactor=False is not implemented (gtsam default is True)")
-        extra = float(extra_error or 0.0)
         poses = poses.to(torch.float64).contiguous().clone()
         points = points.to(torch.float64).contiguous().clone()
         rep = LMReport(setup_seconds=self.P.setup_seconds)
         torch.cuda.synchronize(self.P.device)
         t0 = time.perf_counter()
         lam = prm.lambdaInitial
-        current = self.error(poses, points) + extra
+        current = self.error(poses, points) + (aux.error() if aux else 0.0)
         rep.initial_error = current
         if current <= prm.errorTol or prm.maxIterations <= 0:
             rep.status, rep.final_error, rep.final_lambda = 0, current, lam
@@ -205,13 +205,14 @@ class StereoBASolver:
                 sc = self.scal.cpu()                              # one sync per trial
                 status = int(self.status.item())
                 rep.tries += 1
+                a_lin, a_new = aux.try_lambda(lam) if aux else (0.0, 0.0)
                 if lin0 is None:
-                    lin0 = float(sc[0]) + extra
+                    lin0 = float(sc[0]) + (aux.error() if aux else 0.0)
                 success = False
                 if status == 0 and math.isfinite(float(sc[1])) and math.isfinite(float(sc[2])):
-                    lin_change = lin0 - (float(sc[1]) + extra)
+                    lin_change = lin0 - (float(sc[1]) + a_lin)
                     if lin_change >= 0.0:
-                        new_err = float(sc[2]) + extra
+                        new_err = float(sc[2]) + a_new
                         cost_change = current - new_err
                         if lin_change > 2.220446049250313e-16 * lin0:
                             success = cost_change / lin_change > prm.minModelFidelity
@@ -221,6 +222,8 @@ class StereoBASolver:
                             poses, self.new_poses = self.new_poses, poses
                             points, self.new_points = self.new_points, points
                             new_error = new_err
+                            if aux:
+                                aux.accept()
                 if success:
                     lam = max(prm.lambdaLowerBound, lam / prm.lambdaFactor)
                     accepted = True

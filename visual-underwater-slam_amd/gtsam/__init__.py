@@ -1,0 +1,630 @@
+"""A gtsam-shaped module: the drop-in boundary of the BA hot path.
+
+`/root/reference/batch.py` builds its factor graph and solves it exclusively through the Python
+`gtsam` API (import list batch.py:19-26; graph build :270-305; solve :337; read-back :57-68).  This
+module exposes the same names with the same argument meaning, so that
+
+    import visual_underwater_slam_amd.gtsam as gtsam
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import B, V, X, L
+
+is the only change batch.py needs for the stereo path; `LevenbergMarquardtOptimizer.optimize()` then
+runs on the MI355X kernels (ba.py / csrc/ba.hip).
+
+Scope: GenericStereoFactor3D, PriorFactorPose3 and prior factors on vector
+variables are solved.  ImuFactor / CustomFactor objects can be constructed and added (so batch.py's
+graph-building code runs unchanged) but optimize() refuses a graph that contains them, loudly:
+those are the "next" rows f1/f2, not built yet.
+
+Host-side classes here hold plain numpy values; no BA arithmetic happens in Python.
+Errors surface as RuntimeError, as pybind11 does for gtsam's C++ exceptions.
+"""
+import math
+from typing import Callable, Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import symbol_shorthand  # noqa: F401
+from .symbol_shorthand import symbol, symbolChr, symbolIndex  # noqa: F401
+
+__all__ = [
+    "Point3", "Rot3", "Pose3", "Cal3_S2Stereo", "Cal3_S2", "StereoPoint2", "noiseModel", "imuBias",
+    "GenericStereoFactor3D", "PriorFactorPose3", "PriorFactorVector", "PriorFactorPoint3",
+    "PriorFactorConstantBias", "BetweenFactorConstantBias", "ImuFactor", "CustomFactor",
+    "PreintegrationParams", "PreintegratedImuMeasurements", "NavState", "ISAM2",
+    "NonlinearFactorGraph", "Values", "LevenbergMarquardtParams", "LevenbergMarquardtOptimizer",
+    "StereoFactorBlock", "symbol_shorthand", "symbol",
+]
+
+
+# ---------------------------------------------------------------------------------------------
+# geometry
+def Point3(x=0.0, y=0.0, z=0.0):
+    """gtsam.Point3 is a numpy 3-vector in the Python wrapper (batch.py:46,84,132,166)."""
+    if isinstance(x, (list, tuple, np.ndarray)):
+        return np.asarray(x, dtype=float).reshape(3).copy()
+    return np.array([x, y, z], dtype=float)
+
+
+def _skew(w):
+    return np.array([[0.0, -w[2], w[1]], [w[2], 0.0, -w[0]], [-w[1], w[0], 0.0]])
+
+
+class Rot3:
+    def __init__(self, R=None):
+        self._R = np.eye(3) if R is None else np.asarray(R, dtype=float).reshape(3, 3).copy()
+
+    @staticmethod
+    def Quaternion(w, x, y, z):                    # batch.py:47,131  (w first)
+        n = math.sqrt(w * w + x * x + y * y + z * z)
+        w, x, y, z = w / n, x / n, y / n, z / n
+        return Rot3([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    @staticmethod
+    def Rodrigues(wx, wy=None, wz=None):           # batch.py:190
+        w = np.asarray(wx, dtype=float).reshape(3) if wy is None else np.array([wx, wy, wz], dtype=float)
+        return Rot3.Expmap(w)
+
+    @staticmethod
+    def Expmap(w):
+        w = np.asarray(w, dtype=float).reshape(3)
+        th2 = float(w @ w)
+        K = _skew(w)
+        if th2 <= np.finfo(float).eps:
+            return Rot3(np.eye(3) + K)
+        th = math.sqrt(th2)
+        return Rot3(np.eye(3) + math.sin(th) / th * K + 2.0 * math.sin(0.5 * th) ** 2 / th2 * (K @ K))
+
+    @staticmethod
+    def Rx(t):
+        c, s = math.cos(t), math.sin(t)
+        return Rot3([[1, 0, 0], [0, c, -s], [0, s, c]])
+
+    @staticmethod
+    def Ry(t):
+        c, s = math.cos(t), math.sin(t)
+        return Rot3([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+
+    @staticmethod
+    def Rz(t):
+        c, s = math.cos(t), math.sin(t)
+        return Rot3([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+    @staticmethod
+    def Ypr(y, p, r):
+        return Rot3(Rot3.Rz(y)._R @ Rot3.Ry(p)._R @ Rot3.Rx(r)._R)
+
+    def matrix(self):
+        return self._R.copy()
+
+    def inverse(self):
+        return Rot3(self._R.T)
+
+    def compose(self, other):
+        return Rot3(self._R @ other._R)
+
+    def rotate(self, p):
+        return self._R @ np.asarray(p, dtype=float).reshape(3)
+
+    def __mul__(self, other):
+        return self.compose(other)
+
+    def equals(self, other, tol=1e-9):
+        return bool(np.allclose(self._R, other._R, atol=tol))
+
+    def __repr__(self):
+        return f"Rot3(\n{self._R}\n)"
+
+
+class Pose3:
+    """Camera/body pose: rotation R and translation t (body-to-world), gtsam.Pose3."""
+
+    def __init__(self, r=None, t=None):
+        if r is None:
+            self._R, self._t = np.eye(3), np.zeros(3)
+        elif isinstance(r, Pose3):
+            self._R, self._t = r._R.copy(), r._t.copy()
+        elif isinstance(r, Rot3):
+            self._R = r.matrix()
+            self._t = np.zeros(3) if t is None else np.asarray(t, dtype=float).reshape(3).copy()
+        else:
+            M = np.asarray(r, dtype=float)
+            if M.shape != (4, 4):
+                raise RuntimeError("Pose3(): expected (Rot3, Point3), a 4x4 matrix, or nothing")
+            self._R, self._t = M[:3, :3].copy(), M[:3, 3].copy()
+
+    # accessors used by batch.py:62,134-135,213
+    def x(self):
+        return float(self._t[0])
+
+    def y(self):
+        return float(self._t[1])
+
+    def z(self):
+        return float(self._t[2])
+
+    def rotation(self):
+        return Rot3(self._R)
+
+    def translation(self):
+        return self._t.copy()
+
+    def matrix(self):
+        M = np.eye(4)
+        M[:3, :3], M[:3, 3] = self._R, self._t
+        return M
+
+    def inverse(self):
+        return Pose3(Rot3(self._R.T), -self._R.T @ self._t)
+
+    def compose(self, other):
+        return Pose3(Rot3(self._R @ other._R), self._t + self._R @ other._t)
+
+    def __mul__(self, other):
+        return self.compose(other)
+
+    def between(self, other):
+        return self.inverse().compose(other)
+
+    def transformFrom(self, p):
+        return self._R @ np.asarray(p, dtype=float).reshape(3) + self._t
+
+    def transformTo(self, p):
+        return self._R.T @ (np.asarray(p, dtype=float).reshape(3) - self._t)
+
+    def equals(self, other, tol=1e-9):
+        return bool(np.allclose(self._R, other._R, atol=tol) and np.allclose(self._t, other._t, atol=tol))
+
+    def flat12(self):
+        """Row-major R followed by t: the device layout of include/vus.h."""
+        return np.concatenate([self._R.reshape(-1), self._t])
+
+    @staticmethod
+    def from_flat12(v):
+        v = np.asarray(v, dtype=float).reshape(12)
+        return Pose3(Rot3(v[:9].reshape(3, 3)), v[9:])
+
+    def __repr__(self):
+        return f"Pose3(R=\n{self._R},\n t={self._t})"
+
+
+class Cal3_S2Stereo:
+    def __init__(self, fx=1.0, fy=1.0, s=0.0, u0=0.0, v0=0.0, b=1.0):   # batch.py:115
+        self._v = (float(fx), float(fy), float(s), float(u0), float(v0), float(b))
+
+    def fx(self):
+        return self._v[0]
+
+    def fy(self):
+        return self._v[1]
+
+    def skew(self):
+        return self._v[2]
+
+    def px(self):
+        return self._v[3]
+
+    def py(self):
+        return self._v[4]
+
+    def baseline(self):
+        return self._v[5]
+
+    def vector6(self):
+        return np.array(self._v)
+
+    def equals(self, other, tol=1e-9):
+        return bool(np.allclose(self._v, other._v, atol=tol))
+
+
+class Cal3_S2:
+    def __init__(self, fx=1.0, fy=1.0, s=0.0, u0=0.0, v0=0.0):
+        self._v = (float(fx), float(fy), float(s), float(u0), float(v0))
+
+
+class StereoPoint2:
+    def __init__(self, uL=0.0, uR=0.0, v=0.0):                           # batch.py:301
+        self._m = np.array([uL, uR, v], dtype=float)
+
+    def uL(self):
+        return float(self._m[0])
+
+    def uR(self):
+        return float(self._m[1])
+
+    def v(self):
+        return float(self._m[2])
+
+    def vector(self):
+        return self._m.copy()
+
+
+# ---------------------------------------------------------------------------------------------
+# noise models (batch.py:95-98,118,189)
+class _NoiseModel:
+    def __init__(self, sigmas):
+        self._sigmas = np.asarray(sigmas, dtype=float).reshape(-1).copy()
+        if (self._sigmas <= 0).any():
+            raise RuntimeError("noise model sigmas must be positive")
+
+    def sigmas(self):
+        return self._sigmas.copy()
+
+    def dim(self):
+        return int(self._sigmas.size)
+
+    def is_isotropic(self):
+        return bool(np.all(self._sigmas == self._sigmas[0]))
+
+
+class _Diagonal(_NoiseModel):
+    @staticmethod
+    def Sigmas(sigmas):
+        return _Diagonal(sigmas)
+
+    @staticmethod
+    def Variances(v):
+        return _Diagonal(np.sqrt(np.asarray(v, dtype=float)))
+
+    @staticmethod
+    def Precisions(p):
+        return _Diagonal(1.0 / np.sqrt(np.asarray(p, dtype=float)))
+
+
+class _Isotropic(_NoiseModel):
+    @staticmethod
+    def Sigma(dim, sigma):
+        return _Isotropic(np.full(int(dim), float(sigma)))
+
+    @staticmethod
+    def Variance(dim, variance):
+        return _Isotropic(np.full(int(dim), math.sqrt(float(variance))))
+
+
+class _Unit(_NoiseModel):
+    @staticmethod
+    def Create(dim):
+        return _Unit(np.ones(int(dim)))
+
+
+class noiseModel:  # namespace, as in gtsam
+    Base = _NoiseModel
+    Diagonal = _Diagonal
+    Isotropic = _Isotropic
+    Unit = _Unit
+
+
+class _ConstantBias:
+    def __init__(self, biasAcc=None, biasGyro=None):
+        self._a = np.zeros(3) if biasAcc is None else np.asarray(biasAcc, dtype=float).reshape(3)
+        self._g = np.zeros(3) if biasGyro is None else np.asarray(biasGyro, dtype=float).reshape(3)
+
+    def vector(self):
+        return np.concatenate([self._a, self._g])
+
+    def accelerometer(self):
+        return self._a.copy()
+
+    def gyroscope(self):
+        return self._g.copy()
+
+
+class imuBias:  # namespace (batch.py:92)
+    ConstantBias = _ConstantBias
+
+
+# ---------------------------------------------------------------------------------------------
+# factors
+class _Factor:
+    def __init__(self, keys):
+        self._keys = [int(k) for k in keys]
+
+    def keys(self):
+        return list(self._keys)
+
+    def size(self):
+        return len(self._keys)
+
+
+class GenericStereoFactor3D(_Factor):
+    """GenericStereoFactor<Pose3, Point3>(measured, model, poseKey, landmarkKey, K)  (batch.py:300-304)."""
+
+    def __init__(self, measured: StereoPoint2, model: _NoiseModel, poseKey: int, landmarkKey: int,
+                 K: Cal3_S2Stereo):
+        super().__init__([poseKey, landmarkKey])
+        if model.dim() != 3:
+            raise RuntimeError("GenericStereoFactor3D needs a 3-dimensional noise model")
+        self._measured, self._model, self._K = measured, model, K
+
+    def measured(self):
+        return self._measured
+
+    def calibration(self):
+        return self._K
+
+    def noiseModel(self):
+        return self._model
+
+
+class StereoFactorBlock(_Factor):
+    """EXTENSION (not in gtsam): many GenericStereoFactor3D factors sharing one noise model and one
+    calibration, held as arrays.  It is the vectorised form of the emission loop batch.py:296-305 for
+    graphs with millions of observations, where one Python object per factor is the bottleneck."""
+
+    def __init__(self, measured, model: _NoiseModel, poseKeys, landmarkKeys, K: Cal3_S2Stereo):
+        self.meas = np.ascontiguousarray(measured, dtype=float).reshape(-1, 3)
+        self.pose_keys = np.ascontiguousarray(poseKeys, dtype=np.int64).reshape(-1)
+        self.landmark_keys = np.ascontiguousarray(landmarkKeys, dtype=np.int64).reshape(-1)
+        if not (len(self.meas) == len(self.pose_keys) == len(self.landmark_keys)):
+            raise RuntimeError("StereoFactorBlock: arrays differ in length")
+        if model.dim() != 3:
+            raise RuntimeError("StereoFactorBlock needs a 3-dimensional noise model")
+        self._model, self._K = model, K
+        self._keys = None
+
+    def keys(self):
+        return np.unique(np.concatenate([self.pose_keys, self.landmark_keys])).tolist()
+
+    def size(self):
+        return len(self.meas)
+
+    def __len__(self):
+        return len(self.meas)
+
+
+class _PriorFactor(_Factor):
+    def __init__(self, key, prior, model):
+        super().__init__([key])
+        self._prior, self._model = prior, model
+
+    def prior(self):
+        return self._prior
+
+    def noiseModel(self):
+        return self._model
+
+
+class PriorFactorPose3(_PriorFactor):
+    def __init__(self, key, prior: Pose3, model: _NoiseModel):           # batch.py:281
+        if model.dim() != 6:
+            raise RuntimeError("PriorFactorPose3 needs a 6-dimensional noise model")
+        super().__init__(key, Pose3(prior), model)
+
+
+class PriorFactorVector(_PriorFactor):
+    def __init__(self, key, prior, model: _NoiseModel):                  # batch.py:282
+        prior = np.asarray(prior, dtype=float).reshape(-1).copy()
+        if model.dim() != prior.size:
+            raise RuntimeError("PriorFactorVector: noise model dimension differs from the vector's")
+        super().__init__(key, prior, model)
+
+
+class PriorFactorPoint3(PriorFactorVector):
+    pass
+
+
+class PriorFactorConstantBias(_PriorFactor):
+    def __init__(self, key, prior: _ConstantBias, model: _NoiseModel):
+        super().__init__(key, prior, model)
+
+
+class BetweenFactorConstantBias(_Factor):
+    def __init__(self, key1, key2, measured, model):
+        super().__init__([key1, key2])
+        self._measured, self._model = measured, model
+
+
+class PreintegrationParams:
+    """Holds the IMU noise parameters batch.py sets at :181-187 (consumed by f1, not built yet)."""
+
+    def __init__(self, n_gravity):
+        self.n_gravity = np.asarray(n_gravity, dtype=float)
+        self.accelerometerCovariance = np.eye(3)
+        self.gyroscopeCovariance = np.eye(3)
+        self.integrationCovariance = np.eye(3)
+        self.use2ndOrderCoriolis = False
+        self.omegaCoriolis = np.zeros(3)
+
+    @staticmethod
+    def MakeSharedU(g=9.81):
+        return PreintegrationParams([0.0, 0.0, -float(g)])
+
+    @staticmethod
+    def MakeSharedD(g=9.81):
+        return PreintegrationParams([0.0, 0.0, float(g)])
+
+    def setAccelerometerCovariance(self, c):
+        self.accelerometerCovariance = np.asarray(c, dtype=float)
+
+    def setGyroscopeCovariance(self, c):
+        self.gyroscopeCovariance = np.asarray(c, dtype=float)
+
+    def setIntegrationCovariance(self, c):
+        self.integrationCovariance = np.asarray(c, dtype=float)
+
+    def setUse2ndOrderCoriolis(self, f):
+        self.use2ndOrderCoriolis = bool(f)
+
+    def setOmegaCoriolis(self, w):
+        self.omegaCoriolis = np.asarray(w, dtype=float)
+
+
+class PreintegratedImuMeasurements:
+    """Records the raw samples (batch.py:290) so an ImuFactor can copy them; the preintegration
+    arithmetic itself belongs to row f1 of SURVEY.md section 8 and is not implemented yet."""
+
+    def __init__(self, params: PreintegrationParams, bias: Optional[_ConstantBias] = None):
+        self.params, self.bias = params, bias or _ConstantBias()
+        self.samples: List[np.ndarray] = []
+
+    def integrateMeasurement(self, acc, gyro, dt):
+        self.samples.append(np.concatenate([np.asarray(acc, float), np.asarray(gyro, float), [float(dt)]]))
+
+    def resetIntegration(self):
+        self.samples = []
+
+    def deltaTij(self):
+        return float(sum(s[6] for s in self.samples))
+
+
+class ImuFactor(_Factor):
+    def __init__(self, pose_i, vel_i, pose_j, vel_j, bias, pim: PreintegratedImuMeasurements):   # batch.py:238
+        super().__init__([pose_i, vel_i, pose_j, vel_j, bias])
+        self.samples = [s.copy() for s in pim.samples]     # gtsam copies the PIM: resetIntegration() after is safe
+        self.params = pim.params
+
+
+class CustomFactor(_Factor):
+    def __init__(self, model: _NoiseModel, keys: Sequence[int], error_function: Callable):       # batch.py:245-249
+        super().__init__(keys)
+        self._model, self._fn = model, error_function
+
+
+class NavState:
+    def __init__(self, pose=None, velocity=None):
+        self._pose, self._v = pose or Pose3(), np.zeros(3) if velocity is None else np.asarray(velocity, float)
+
+
+class ISAM2:
+    """Constructed but never used by batch.py (batch.py:79); iSAM2 is out of scope."""
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def update(self, *args, **kwargs):
+        raise NotImplementedError("ISAM2 is outside the hot path (isam.py is declared broken: README.md:40-41)")
+
+
+# ---------------------------------------------------------------------------------------------
+# containers
+class Values:
+    def __init__(self, other: Optional["Values"] = None):
+        self._d: Dict[int, object] = dict(other._d) if other is not None else {}
+
+    def insert(self, key, value):                                        # batch.py:274,283-288,298
+        key = int(key)
+        if key in self._d:
+            raise RuntimeError(f"Attempting to add a key-value pair with key \"{symbol_shorthand.key_string(key)}\", "
+                               "which already exists in the Values.")
+        self._d[key] = self._coerce(value)
+
+    def update(self, key, value):
+        key = int(key)
+        if key not in self._d:
+            raise RuntimeError(f"Requested to update a key-value pair with key \"{symbol_shorthand.key_string(key)}\", "
+                               "which does not exist in the Values.")
+        self._d[key] = self._coerce(value)
+
+    def insert_or_assign(self, key, value):
+        self._d[int(key)] = self._coerce(value)
+
+    @staticmethod
+    def _coerce(value):
+        if isinstance(value, (Pose3, Rot3, _ConstantBias)):
+            return value
+        return np.asarray(value, dtype=float).reshape(-1).copy()
+
+    def exists(self, key):                                               # batch.py:60,297
+        return int(key) in self._d
+
+    def erase(self, key):
+        if int(key) not in self._d:
+            raise RuntimeError(f"key \"{symbol_shorthand.key_string(int(key))}\" does not exist in the Values")
+        del self._d[int(key)]
+
+    def _at(self, key, kind, name):
+        key = int(key)
+        if key not in self._d:
+            raise RuntimeError(f"Attempting to {name} the key \"{symbol_shorthand.key_string(key)}\", "
+                               "which does not exist in the Values.")
+        v = self._d[key]
+        if not isinstance(v, kind):
+            raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(key)}\" holds a "
+                               f"{type(v).__name__}, not what {name} asks for")
+        return v
+
+    def atPose3(self, key):                                              # batch.py:61,211
+        return self._at(key, Pose3, "atPose3")
+
+    def atVector(self, key):                                             # batch.py:210
+        return self._at(key, np.ndarray, "atVector").copy()
+
+    def atPoint3(self, key):
+        v = self._at(key, np.ndarray, "atPoint3")
+        if v.size != 3:
+            raise RuntimeError("atPoint3: value is not a 3-vector")
+        return v.copy()
+
+    def atConstantBias(self, key):
+        return self._at(key, _ConstantBias, "atConstantBias")
+
+    def keys(self):
+        return sorted(self._d)
+
+    def size(self):
+        return len(self._d)
+
+    def __len__(self):
+        return len(self._d)
+
+    # EXTENSION: bulk insertion of landmark points (vectorised batch.py:297-298)
+    def insert_points(self, keys, points):
+        pts = np.asarray(points, dtype=float).reshape(-1, 3)
+        for k, p in zip(np.asarray(keys).reshape(-1).tolist(), pts):
+            self.insert(k, p)
+
+
+class NonlinearFactorGraph:
+    def __init__(self):
+        self._factors: List[_Factor] = []
+
+    def add(self, factor):                                               # batch.py:281-282
+        self._factors.append(factor)
+
+    def push_back(self, factor):                                         # batch.py:291,292,305
+        self._factors.append(factor)
+
+    def size(self):
+        return len(self._factors)
+
+    def nrFactors(self):
+        return sum(f.size() if isinstance(f, StereoFactorBlock) else 1 for f in self._factors)
+
+    def at(self, i):
+        return self._factors[i]
+
+    def keys(self):
+        out = set()
+        for f in self._factors:
+            out.update(f.keys())
+        return sorted(out)
+
+    def error(self, values: Values) -> float:
+        """0.5 * sum of squared whitened residuals, evaluated on the GPU."""
+        from .optimizer import graph_error
+        return graph_error(self, values)
+
+    def saveGraph(self, path, values=None):                              # batch.py:338
+        """Graphviz DOT of the factor graph (variables as circles, factors as dots)."""
+        ks = self.keys()
+        with open(path, "w") as f:
+            f.write("graph {\n  size=\"5,5\";\n\n")
+            for k in ks:
+                f.write(f"  var{k}[label=\"{symbol_shorthand.key_string(k)}\"];\n")
+            f.write("\n")
+            n = 0
+            for fac in self._factors:
+                if isinstance(fac, StereoFactorBlock):
+                    for pk, lk in zip(fac.pose_keys.tolist(), fac.landmark_keys.tolist()):
+                        f.write(f"  factor{n}[label=\"\", shape=point];\n  var{pk}--factor{n};\n  var{lk}--factor{n};\n")
+                        n += 1
+                    continue
+                f.write(f"  factor{n}[label=\"\", shape=point];\n")
+                for k in fac.keys():
+                    f.write(f"  var{k}--factor{n};\n")
+                n += 1
+            f.write("}\n")
+
+
+from .optimizer import LevenbergMarquardtParams, LevenbergMarquardtOptimizer  # noqa: E402

@@ -1,0 +1,250 @@
+"""LevenbergMarquardtParams / LevenbergMarquardtOptimizer with gtsam's names and defaults
+(/root/reference/batch.py:337), backed by the HIP bundle-adjustment kernels (../ba.py).
+
+Host work here is graph -> structure-of-arrays packing (the vectorised form of batch.py:295-305);
+every residual, Jacobian, linear solve and error is computed on the GPU.
+"""
+import math
+from typing import List, Optional
+
+import numpy as np
+
+from . import symbol_shorthand as _sym
+
+
+class LevenbergMarquardtParams:
+    """gtsam.LevenbergMarquardtParams(): same defaults, same setter/getter names."""
+
+    def __init__(self):
+        self.lambdaInitial = 1e-5
+        self.lambdaFactor = 10.0
+        self.lambdaUpperBound = 1e5
+        self.lambdaLowerBound = 0.0
+        self.minModelFidelity = 1e-3
+        self.diagonalDamping = False
+        self.useFixedLambdaFactor = True
+        self.maxIterations = 100
+        self.relativeErrorTol = 1e-5
+        self.absoluteErrorTol = 1e-5
+        self.errorTol = 0.0
+        self.verbosity = "SILENT"
+        self.verbosityLM = "SILENT"
+
+    # gtsam's accessor spelling
+    def setlambdaInitial(self, v): self.lambdaInitial = float(v)
+    def setlambdaFactor(self, v): self.lambdaFactor = float(v)
+    def setlambdaUpperBound(self, v): self.lambdaUpperBound = float(v)
+    def setlambdaLowerBound(self, v): self.lambdaLowerBound = float(v)
+    def setDiagonalDamping(self, v): self.diagonalDamping = bool(v)
+    def setUseFixedLambdaFactor(self, v): self.useFixedLambdaFactor = bool(v)
+    def setMaxIterations(self, v): self.maxIterations = int(v)
+    def setRelativeErrorTol(self, v): self.relativeErrorTol = float(v)
+    def setAbsoluteErrorTol(self, v): self.absoluteErrorTol = float(v)
+    def setErrorTol(self, v): self.errorTol = float(v)
+    def setVerbosity(self, v): self.verbosity = str(v)
+    def setVerbosityLM(self, v): self.verbosityLM = str(v)
+    def getlambdaInitial(self): return self.lambdaInitial
+    def getlambdaFactor(self): return self.lambdaFactor
+    def getlambdaUpperBound(self): return self.lambdaUpperBound
+    def getlambdaLowerBound(self): return self.lambdaLowerBound
+    def getDiagonalDamping(self): return self.diagonalDamping
+    def getMaxIterations(self): return self.maxIterations
+    def getRelativeErrorTol(self): return self.relativeErrorTol
+    def getAbsoluteErrorTol(self): return self.absoluteErrorTol
+    def getErrorTol(self): return self.errorTol
+
+    def _to_lm(self):
+        from ..ba import LMParams
+        return LMParams(self.lambdaInitial, self.lambdaFactor, self.lambdaUpperBound, self.lambdaLowerBound,
+                        self.minModelFidelity, self.maxIterations, self.relativeErrorTol, self.absoluteErrorTol,
+                        self.errorTol, self.diagonalDamping, self.useFixedLambdaFactor)
+
+
+class _AuxPriors:
+    """Vector variables constrained only by PriorFactorVector: they decouple from the camera system,
+    so their damped step is closed-form per coordinate; kept on the host (O(#such variables))."""
+
+    def __init__(self):
+        self.keys: List[int] = []
+        self.x: List[np.ndarray] = []
+        self.prior: List[np.ndarray] = []
+        self.w: List[np.ndarray] = []
+        self._cand = None
+
+    def add(self, key, x, prior, sigmas):
+        self.keys.append(key); self.x.append(x.copy()); self.prior.append(prior.copy()); self.w.append(1.0 / sigmas)
+
+    def error(self):
+        return sum(0.5 * float(np.sum((w * (x - p)) ** 2)) for x, p, w in zip(self.x, self.prior, self.w))
+
+    def try_lambda(self, lam):
+        """returns (linearised error at the damped step, nonlinear error at the new values)"""
+        lin, new, self._cand = 0.0, 0.0, []
+        for x, p, w in zip(self.x, self.prior, self.w):
+            r = w * (x - p)
+            d = -(w * r) / (w * w + lam)
+            self._cand.append(x + d)
+            lin += 0.5 * float(np.sum((r + w * d) ** 2))
+            new += 0.5 * float(np.sum((w * (x + d - p)) ** 2))
+        return lin, new
+
+    def accept(self):
+        self.x = self._cand
+
+
+def _pack_graph(graph, values):
+    """Factor graph + Values -> arrays for StereoBAProblem.  Raises on anything outside the built scope."""
+    from . import (GenericStereoFactor3D, StereoFactorBlock, PriorFactorPose3, PriorFactorVector, Pose3,
+                   ImuFactor, CustomFactor)
+    meas, pkeys, lkeys = [], [], []
+    model_sigma, calib = None, None
+    prior_pose, prior_vec = [], []
+    single_m, single_p, single_l = [], [], []
+
+    def check_model(model, K):
+        nonlocal model_sigma, calib
+        if not model.is_isotropic():
+            raise NotImplementedError("stereo factors need an isotropic noise model (batch.py:118 uses Isotropic.Sigma(3, 10))")
+        s = float(model.sigmas()[0])
+        if model_sigma is None:
+            model_sigma, calib = s, K
+        elif s != model_sigma or not K.equals(calib):
+            raise NotImplementedError("all stereo factors of one graph must share one noise model and one Cal3_S2Stereo")
+
+    for i in range(graph.size()):
+        f = graph.at(i)
+        if isinstance(f, StereoFactorBlock):
+            check_model(f._model, f._K)
+            meas.append(f.meas); pkeys.append(f.pose_keys); lkeys.append(f.landmark_keys)
+        elif isinstance(f, GenericStereoFactor3D):
+            check_model(f._model, f._K)
+            single_m.append(f._measured._m); single_p.append(f._keys[0]); single_l.append(f._keys[1])
+        elif isinstance(f, PriorFactorPose3):
+            prior_pose.append(f)
+        elif isinstance(f, PriorFactorVector):
+            prior_vec.append(f)
+        elif isinstance(f, (ImuFactor, CustomFactor)):
+            raise NotImplementedError(
+                f"{type(f).__name__} is not built yet (SURVEY.md section 8, rows f1/f2): this round solves graphs of "
+                "GenericStereoFactor3D + PriorFactorPose3 (+ decoupled PriorFactorVector) on the GPU")
+        else:
+            raise NotImplementedError(f"factor type {type(f).__name__} is not supported by the MI355X optimizer")
+    if single_m:
+        meas.append(np.asarray(single_m, dtype=float).reshape(-1, 3))
+        pkeys.append(np.asarray(single_p, dtype=np.int64)); lkeys.append(np.asarray(single_l, dtype=np.int64))
+    meas = np.concatenate(meas) if meas else np.zeros((0, 3))
+    pkeys = np.concatenate(pkeys) if pkeys else np.zeros(0, np.int64)
+    lkeys = np.concatenate(lkeys) if lkeys else np.zeros(0, np.int64)
+
+    pose_keys = np.array(sorted(k for k in values.keys() if isinstance(values._d[k], Pose3)), dtype=np.int64)
+    if len(pose_keys) == 0:
+        raise RuntimeError("the Values hold no Pose3 variable")
+    lm_keys = np.unique(lkeys)
+    for k in np.unique(pkeys).tolist():
+        if not values.exists(k) or not isinstance(values._d[k], Pose3):
+            raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(k)}\", which does not exist in the Values.")
+    pose_idx = np.searchsorted(pose_keys, pkeys).astype(np.int32)
+    lm_idx = np.searchsorted(lm_keys, lkeys).astype(np.int32)
+    points = np.empty((len(lm_keys), 3))
+    for j, k in enumerate(lm_keys.tolist()):
+        if not values.exists(k):
+            raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(k)}\", which does not exist in the Values.")
+        v = values._d[k]
+        if not isinstance(v, np.ndarray) or v.size != 3:
+            raise RuntimeError(f"landmark \"{_sym.key_string(k)}\" is not a Point3")
+        points[j] = v
+    poses = np.stack([values._d[k].flat12() for k in pose_keys.tolist()])
+
+    pr_idx, pr_T, pr_s = [], [], []
+    for f in prior_pose:
+        k = f._keys[0]
+        j = int(np.searchsorted(pose_keys, k))
+        if j >= len(pose_keys) or pose_keys[j] != k:
+            raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(k)}\", which does not exist in the Values.")
+        pr_idx.append(j); pr_T.append(f._prior.flat12()); pr_s.append(f._model.sigmas())
+    aux = _AuxPriors()
+    lm_set = set(lm_keys.tolist())
+    for f in prior_vec:
+        k = f._keys[0]
+        if k in lm_set:
+            raise NotImplementedError("a prior factor on a landmark observed by stereo factors is not supported yet")
+        if not values.exists(k):
+            raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(k)}\", which does not exist in the Values.")
+        aux.add(k, values.atVector(k), f._prior, f._model.sigmas())
+    if len(set(aux.keys)) != len(aux.keys):
+        raise NotImplementedError("several prior factors on one vector variable are not supported")
+    return dict(meas=meas, pose_idx=pose_idx, lm_idx=lm_idx, pose_keys=pose_keys, lm_keys=lm_keys, poses=poses,
+                points=points, sigma=model_sigma if model_sigma is not None else 1.0,
+                K=calib.vector6() if calib is not None else np.array([1.0, 1.0, 0.0, 0.0, 0.0, 1.0]),
+                prior_idx=np.asarray(pr_idx, np.int32), prior_T=np.asarray(pr_T, float).reshape(-1, 12),
+                prior_sigmas=np.asarray(pr_s, float).reshape(-1, 6), aux=aux)
+
+
+def _build_solver(pg, device="cuda:0"):
+    from ..ba import StereoBAProblem, StereoBASolver
+    prob = StereoBAProblem(pg["pose_idx"], pg["lm_idx"], pg["meas"], len(pg["pose_keys"]), len(pg["lm_keys"]),
+                           pg["K"], pg["sigma"], prior_pose=pg["prior_idx"], prior_T=pg["prior_T"],
+                           prior_sigmas=pg["prior_sigmas"], device=device)
+    return prob, StereoBASolver(prob)
+
+
+def graph_error(graph, values) -> float:
+    import torch
+    pg = _pack_graph(graph, values)
+    prob, sv = _build_solver(pg)
+    e = sv.error(torch.from_numpy(pg["poses"]).to(prob.device), torch.from_numpy(pg["points"]).to(prob.device))
+    return e + pg["aux"].error()
+
+
+class LevenbergMarquardtOptimizer:
+    """gtsam.LevenbergMarquardtOptimizer(graph, initialValues, params=LevenbergMarquardtParams())."""
+
+    def __init__(self, graph, initialValues, params: Optional[LevenbergMarquardtParams] = None, device="cuda:0"):
+        self._graph, self._initial = graph, initialValues
+        self._params = params or LevenbergMarquardtParams()
+        self._device = device
+        self._result = None
+        self._report = None
+
+    def optimize(self):
+        """Runs LM to convergence and returns a NEW Values; the inputs are left untouched."""
+        import torch
+        from . import Values, Pose3
+        pg = _pack_graph(self._graph, self._initial)
+        prob, sv = _build_solver(pg, self._device)
+        aux = pg["aux"] if pg["aux"].keys else None
+        poses, points, rep = sv.optimize(torch.from_numpy(pg["poses"]).to(prob.device),
+                                         torch.from_numpy(pg["points"]).to(prob.device),
+                                         self._params._to_lm(), aux=aux)
+        poses, points = poses.cpu().numpy(), points.cpu().numpy()
+        out = Values(self._initial)
+        for k, T in zip(pg["pose_keys"].tolist(), poses):
+            out._d[k] = Pose3.from_flat12(T)
+        for k, p in zip(pg["lm_keys"].tolist(), points):
+            out._d[k] = p.copy()
+        if aux is not None:
+            for k, x in zip(aux.keys, aux.x):
+                out._d[k] = x.copy()
+        self._result, self._report = out, rep
+        return out
+
+    def optimizeSafely(self):
+        return self.optimize()
+
+    def values(self):
+        return self._result if self._result is not None else self._initial
+
+    def error(self):
+        if self._report is not None:
+            return self._report.final_error
+        return graph_error(self._graph, self._initial)
+
+    def iterations(self):
+        return 0 if self._report is None else self._report.iterations
+
+    def lambda_(self):
+        return self._params.lambdaInitial if self._report is None else self._report.final_lambda
+
+    def report(self):
+        """EXTENSION: the LMReport of the last optimize() (error / lambda history, timings)."""
+        return self._report
