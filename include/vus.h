@@ -161,6 +161,11 @@ int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lamb
                  const double* W, const double* V, const double* gl, const double* Hpp,
                  const double* gp, double* Vinv, double* Y, double* Sband, double* gs, void* stream);
 
+/* Sband(i,i) += value * I for every pose.  Used by the landmark-sharded multi-GPU solve: after the
+ * all-reduce of the per-rank bands the pose damping lambda*I has been added once per rank, and
+ * value = -(n_ranks-1)*lambda restores a single copy. */
+int vus_ba_add_diag(double* Sband, int n_poses, int band, double value, void* stream);
+
 /* Solve S dp = -gs by block-band Cholesky (Sband is overwritten by its factor).
  * status[0] = 0 ok, k+1 = non-positive pivot met in scalar column k (dp is then undefined). */
 int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, double* dp,

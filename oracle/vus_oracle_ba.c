@@ -314,6 +314,13 @@ int vus_ba_schur_cpu(const vus_ba_problem* P, const vus_ba_structure* S, double 
   return VUS_OK;
 }
 
+int vus_ba_add_diag_cpu(double* Sband, int n_poses, int band, double value) {
+  if (!Sband || n_poses < 1 || band < 0) return VUS_E_INVALID;
+  for (int i = 0; i < n_poses; ++i)
+    for (int k = 0; k < 6; ++k) Sband[36 * (size_t)i * (band + 1) + 7 * k] += value;
+  return VUS_OK;
+}
+
 /* scalar view of the block band: element (R, C), R >= C, R/6 - C/6 <= B */
 static inline double* band_at(double* Sb, int B, int R, int C) {
   int i = R / 6, k = C / 6;

@@ -1,0 +1,164 @@
+"""Multi-rank paths: sharding logic and collectives, rehearsed with world_size-2 gloo process groups.
+CPU tests use the oracle as the per-rank compute (the HIP kernels need a GPU); the GPU-marked test
+runs the real ShardedStereoBASolver as two ranks on the one visible MI355X."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from visual_underwater_slam_amd import synth, ba_pack
+from visual_underwater_slam_amd import dist as vdist
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _run(fn, world, *args):
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_entry, args=(fn, r, world, port, q, args)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(60)
+    for o in out:
+        if isinstance(o[1], str) and o[1].startswith("ERR"):
+            raise AssertionError(o[1])
+    return dict(out)
+
+
+def _entry(fn, rank, world, port, q, args):
+    import traceback
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        q.put((rank, fn(rank, world, *args)))
+        dist.destroy_process_group()
+    except Exception:
+        q.put((rank, "ERR " + traceback.format_exc()))
+
+
+def test_shard_frames_covers_every_frame_and_pair_once():
+    for n, w in [(1000, 8), (10, 3), (5, 8), (1, 2), (17, 4)]:
+        owned, pairs = [], []
+        for r in range(w):
+            first, n_owned, n_halo = vdist.shard_frames(n, w, r)
+            owned += list(range(first, first + n_owned))
+            pairs += [(t, t + 1) for t in range(first, first + n_halo - 1)]
+            assert n_halo - n_owned in (0, 1)
+        assert owned == list(range(n))
+        assert sorted(pairs) == [(t, t + 1) for t in range(n - 1)]
+
+
+def test_shard_landmarks_partitions_and_balances():
+    seq = synth.ba_sequence(30, 300, 60)
+    op, ol = torch.from_numpy(seq["obs_pose"]), torch.from_numpy(seq["obs_point"])
+    nL = len(seq["points_gt"])
+    for w in (1, 2, 3, 8):
+        b = vdist.shard_landmarks(ol, nL, w)
+        assert b[0] == 0 and b[-1] == nL and all(x <= y for x, y in zip(b, b[1:]))
+        n = [int(((ol >= b[r]) & (ol < b[r + 1])).sum()) for r in range(w)]
+        assert sum(n) == len(ol) and max(n) - min(n) <= len(ol) / w * 0.25 + 60
+    assert vdist.global_band(op, ol, nL) == ba_pack.build_structure(
+        ba_pack.pack_observations(op, ol, torch.from_numpy(seq["meas"]), 30, nL))["band"]
+
+
+def _gather_worker(rank, world, n_frames, K):
+    first, n_owned, _ = vdist.shard_frames(n_frames, world, rank)
+    rows = torch.arange(first, first + n_owned, dtype=torch.int32)[:, None]
+    s = rows * 10 + torch.arange(K, dtype=torch.int32)[None]
+    a, b, c = vdist.gather_tracks(s, s + 1, s + 2, n_frames, world, rank)
+    return a.numpy(), b.numpy(), c.numpy()
+
+
+def test_gather_tracks_gloo_world2():
+    out = _run(_gather_worker, 2, 7, 5)
+    exp = np.arange(7, dtype=np.int32)[:, None] * 10 + np.arange(5, dtype=np.int32)[None]
+    for r in range(2):
+        assert np.array_equal(out[r][0], exp) and np.array_equal(out[r][1], exp + 1) and np.array_equal(out[r][2], exp + 2)
+
+
+def _sharded_oracle_worker(rank, world, lam):
+    """Each rank: oracle linearise + Schur on ITS landmarks, then the product's collectives."""
+    from oracle import oracle as O
+    seq = synth.ba_sequence(40, 400, 80)
+    nP, nL = 40, len(seq["points_gt"])
+    op, ol, me = torch.from_numpy(seq["obs_pose"]), torch.from_numpy(seq["obs_point"]), torch.from_numpy(seq["meas"])
+    band = vdist.global_band(op, ol, nL)
+    sop, sol, sme, lo, hi = vdist.shard_observations(op, ol, me, nL, world, rank)
+    pk = ba_pack.pack_observations(sop, sol, sme, nP, hi - lo)
+    pri = (np.array([0], np.int32), seq["poses_gt"][:1], seq["prior_sigmas"][None]) if rank == 0 else None
+    P = O.BAProblem(pk, seq["K"], seq["sigma"], pri)
+    lin = O.ba_linearize(P, seq["poses_init"], seq["points_init"][lo:hi])
+    sch = O.ba_schur(P, band, lam, lin)
+    S, gs, err = torch.from_numpy(sch["Sband"]), torch.from_numpy(sch["gs"]), torch.tensor([lin["err"]], dtype=torch.float64)
+    vdist.allreduce_sum(S); vdist.allreduce_sum(gs); vdist.allreduce_sum(err)
+    Sn = S.numpy()
+    O.lib().vus_ba_add_diag_cpu(O._p(Sn), nP, band, O.c_double(-(world - 1) * lam))
+    dp, status, _ = O.ba_band_solve(Sn, gs.numpy())
+    dl = O.ba_backsub(P, lin, sch["Vinv"], dp)
+    full = torch.zeros((nL, 3), dtype=torch.float64)
+    full[lo:hi] = torch.from_numpy(dl)
+    vdist.allreduce_sum(full)
+    return Sn, gs.numpy(), float(err[0]), dp, full.numpy(), status
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_landmark_sharded_schur_allreduce_equals_single_rank(oracle, world):
+    lam = 0.37
+    out = _run(_sharded_oracle_worker, world, lam)
+    seq = synth.ba_sequence(40, 400, 80)
+    nL = len(seq["points_gt"])
+    pk = ba_pack.pack_observations(torch.from_numpy(seq["obs_pose"]), torch.from_numpy(seq["obs_point"]),
+                                   torch.from_numpy(seq["meas"]), 40, nL)
+    st = ba_pack.build_structure(pk)
+    P = oracle.BAProblem(pk, seq["K"], seq["sigma"], (np.array([0], np.int32), seq["poses_gt"][:1], seq["prior_sigmas"][None]))
+    lin = oracle.ba_linearize(P, seq["poses_init"], seq["points_init"])
+    sch = oracle.ba_schur(P, st["band"], lam, lin)
+    dp, status, _ = oracle.ba_band_solve(sch["Sband"], sch["gs"])
+    dl = oracle.ba_backsub(P, lin, sch["Vinv"], dp)
+    for r in range(world):
+        S, gs, err, dpr, dlr, str_ = out[r]
+        scale = np.abs(sch["Sband"]).max()
+        assert np.abs(S - sch["Sband"]).max() < 1e-9 * scale          # fp64 reduction-order noise only
+        assert np.allclose(gs, sch["gs"], rtol=1e-9, atol=1e-9 * np.abs(sch["gs"]).max())
+        assert np.isclose(err, lin["err"], rtol=1e-12) and str_ == 0
+        assert np.allclose(dpr, dp, rtol=1e-6, atol=1e-9 * np.abs(dp).max())
+        assert np.allclose(dlr, dl, rtol=1e-6, atol=1e-9 * np.abs(dl).max())
+    assert np.array_equal(out[0][3], out[1][3])                       # replicated solve: identical on every rank
+
+
+def _gpu_sharded_worker(rank, world):
+    torch.cuda.set_device(0)
+    seq = synth.ba_sequence(60, 900, 150)
+    nL = len(seq["points_gt"])
+    sv = vdist.ShardedStereoBASolver(seq["obs_pose"], seq["obs_point"], seq["meas"], 60, nL, seq["K"], seq["sigma"],
+                                     prior_pose=[0], prior_T=seq["poses_gt"][:1], prior_sigmas=seq["prior_sigmas"][None])
+    poses, pts_local, rep = sv.optimize(torch.from_numpy(seq["poses_init"]).cuda(), torch.from_numpy(seq["points_init"]).cuda())
+    pts = sv.gather_points(pts_local, nL)
+    return poses.cpu().numpy(), pts.cpu().numpy(), rep.err_hist, rep.tries
+
+
+@pytest.mark.gpu
+def test_sharded_lm_two_ranks_on_one_gpu_matches_single(gpu):
+    from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
+    out = _run(_gpu_sharded_worker, 2)
+    seq = synth.ba_sequence(60, 900, 150)
+    nL = len(seq["points_gt"])
+    prob = StereoBAProblem(seq["obs_pose"], seq["obs_point"], seq["meas"], 60, nL, seq["K"], seq["sigma"],
+                           prior_pose=[0], prior_T=seq["poses_gt"][:1], prior_sigmas=seq["prior_sigmas"][None])
+    poses, points, rep = StereoBASolver(prob).optimize(torch.from_numpy(seq["poses_init"]).cuda(),
+                                                      torch.from_numpy(seq["points_init"]).cuda())
+    for r in range(2):
+        p, pt, hist, tries = out[r]
+        assert tries == rep.tries and np.allclose(hist, rep.err_hist, rtol=1e-9)
+        assert np.abs(p - poses.cpu().numpy()).max() < 1e-9 * max(1.0, np.abs(p).max())     # 1e-9 rel
+        assert np.abs(pt - points.cpu().numpy()).max() < 1e-8 * np.abs(pt).max()
+    assert np.array_equal(out[0][0], out[1][0])

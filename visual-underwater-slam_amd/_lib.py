@@ -20,6 +20,7 @@ SIGNATURES = {
     # bundle adjustment (struct arguments are passed by address)
     "vus_ba_linearize": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "vus_ba_schur": [_P, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "vus_ba_add_diag": [_P, c_int, c_int, c_double, _P],
     "vus_ba_band_solve": [_P, c_int, c_int, _P, _P, _P, _P],
     "vus_ba_backsub": [_P, _P, _P, _P, _P, _P, _P],
     "vus_ba_eval_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

@@ -73,7 +73,7 @@ class StereoBAProblem:
     """Packed, device-resident stereo BA problem (vus_ba_problem + vus_ba_structure)."""
 
     def __init__(self, obs_pose, obs_point, meas, n_poses, n_points, K, sigma, prior_pose=None,
-                 prior_T=None, prior_sigmas=None, device="cuda:0"):
+                 prior_T=None, prior_sigmas=None, device="cuda:0", band=None):
         _lib.require_gpu()
         _lib.load()
         dev = torch.device(device)
@@ -87,6 +87,10 @@ class StereoBAProblem:
         self.pk, self.st = pk, st
         self.device = dev
         self.n_poses, self.n_points, self.n_obs = int(n_poses), int(n_points), pk["n_obs"]
+        if band is not None:            # landmark-sharded solve: every rank allocates the global band
+            if band < st["band"]:
+                raise ValueError(f"band={band} is smaller than this problem's own band {st['band']}")
+            st["band"] = int(band)
         self.band = st["band"]
         self.K = to_dev(K, torch.float64)
         assert self.K.numel() == 6

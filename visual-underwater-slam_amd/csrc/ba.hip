@@ -629,6 +629,11 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(const double
   }
 }
 
+__global__ void add_diag_kernel(double* __restrict__ Sband, int n_poses, int band, double value) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 6 * n_poses) Sband[36 * (size_t)(t / 6) * (band + 1) + 7 * (t % 6)] += value;
+}
+
 __global__ void negate_copy_kernel(const double* __restrict__ src, double* __restrict__ dst, int n) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < n) dst[t] = -src[t];
@@ -809,6 +814,14 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
   if (S->n_blocks > 0) schur_blocks_kernel<<<cdiv(S->n_blocks, 4), 256, 0, st>>>(*S, W, Y, Sband);
   schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, Y, gl, gp, gs);
   VUS_CHECK_LAUNCH("ba_schur");
+  return VUS_OK;
+}
+
+extern "C" int vus_ba_add_diag(double* Sband, int n_poses, int band, double value, void* stream) {
+  VUS_REQUIRE(Sband != nullptr, "Sband is null");
+  VUS_REQUIRE(n_poses >= 1 && band >= 0, "n_poses=%d band=%d", n_poses, band);
+  add_diag_kernel<<<cdiv(6ll * n_poses, 256), 256, 0, vus::as_stream(stream)>>>(Sband, n_poses, band, value);
+  VUS_CHECK_LAUNCH("ba_add_diag");
   return VUS_OK;
 }
 

@@ -1,0 +1,176 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed (backend "nccl" =
+RCCL over xGMI on MI355X; "gloo" for the CPU rehearsals in tests/).
+
+The reference has no distributed code at all (single Python process); these are
+the two places where the path shards:
+
+  front-end  frames are independent -> contiguous chunks of frames per rank with a one-frame halo so
+             that every left(t)->left(t+1) pair is matched by exactly one rank; no collective on the
+             data path, one all_gather of the fixed-size per-frame match records at the end;
+  BA         landmarks are independent given the poses -> contiguous landmark ranges ("landmark
+             block-rows") per rank, poses replicated.  Each rank linearises and eliminates its own
+             landmarks; the exchange step is ONE all-reduce per lambda trial of the reduced camera
+             system (block band + right-hand side), then the band solve is replicated and the
+             back-substitution is local.  Error scalars are all-reduced for the accept test.
+"""
+from typing import List, Tuple
+
+import torch
+import torch.distributed as dist
+
+from . import _lib
+
+
+# ---------------------------------------------------------------------------------------------
+# front-end: frame sharding
+def shard_frames(n_frames: int, world: int, rank: int, halo: int = 1) -> Tuple[int, int, int]:
+    """Contiguous frame range of `rank`: returns (first, n_owned, n_with_halo).  The owner of frame t
+    also owns the temporal pair (t, t+1); it therefore reads `halo` extra frames past its range
+    (none for the last non-empty shard)."""
+    base, rem = divmod(n_frames, world)
+    n_owned = base + (1 if rank < rem else 0)
+    first = rank * base + min(rank, rem)
+    n_halo = min(halo, max(0, n_frames - (first + n_owned))) if n_owned > 0 else 0
+    return first, n_owned, n_owned + n_halo
+
+
+def gather_tracks(stereo_idx: torch.Tensor, track_idx: torch.Tensor, kp_keys_left: torch.Tensor,
+                  n_frames: int, world: int, rank: int):
+    """all_gather of the per-frame feature-track records (BASELINE.json configs[3]).  Inputs are this
+    rank's owned rows: stereo_idx [n_owned, K], track_idx [n_owned, K] (row of the last frame of the
+    stream is all -1), kp_keys_left [n_owned, K].  Returns the three full [n_frames, K] tensors."""
+    K = stereo_idx.shape[1]
+    counts = [shard_frames(n_frames, world, r)[1] for r in range(world)]
+    mx = max(counts)
+    outs = []
+    for t in (stereo_idx, track_idx, kp_keys_left):
+        pad = torch.full((mx, K), -1, dtype=t.dtype, device=t.device)
+        pad[:t.shape[0]] = t
+        if world > 1:
+            bufs = [torch.empty_like(pad) for _ in range(world)]
+            dist.all_gather(bufs, pad)
+        else:
+            bufs = [pad]
+        outs.append(torch.cat([b[:c] for b, c in zip(bufs, counts)], 0))
+    return tuple(outs)
+
+
+# ---------------------------------------------------------------------------------------------
+# BA: landmark block-row sharding
+def shard_landmarks(obs_point: torch.Tensor, n_points: int, world: int) -> List[int]:
+    """Split points 0..n_points-1 into `world` contiguous ranges of roughly equal OBSERVATION count.
+    Returns the world+1 range boundaries."""
+    counts = torch.bincount(obs_point.to(torch.int64), minlength=n_points)
+    cum = torch.cumsum(counts, 0)
+    total = int(cum[-1].item()) if n_points > 0 else 0
+    bounds = [0]
+    for r in range(1, world):
+        target = total * r // world
+        b = int(torch.searchsorted(cum, torch.tensor(target, device=cum.device), right=False).item())
+        bounds.append(max(bounds[-1], min(b, n_points)))
+    bounds.append(n_points)
+    return bounds
+
+
+def shard_observations(obs_pose, obs_point, meas, n_points: int, world: int, rank: int):
+    """This rank's observations with landmark indices renumbered to its local range.
+    Returns (obs_pose, obs_point_local, meas, lo, hi)."""
+    bounds = shard_landmarks(obs_point, n_points, world)
+    lo, hi = bounds[rank], bounds[rank + 1]
+    sel = (obs_point >= lo) & (obs_point < hi)
+    return obs_pose[sel], obs_point[sel] - lo, meas[sel], lo, hi
+
+
+def global_band(obs_pose, obs_point, n_points: int) -> int:
+    """Half-bandwidth (in pose blocks) of the full reduced camera system: every rank must allocate
+    the same band for the all-reduce."""
+    if obs_pose.numel() == 0:
+        return 0
+    op, ol = obs_pose.to(torch.int64), obs_point.to(torch.int64)
+    big = int(op.max().item()) + 1
+    mn = torch.full((n_points,), big, dtype=torch.int64, device=op.device).scatter_reduce(0, ol, op, "amin")
+    mx = torch.zeros((n_points,), dtype=torch.int64, device=op.device).scatter_reduce(0, ol, op, "amax")
+    seen = mn < big
+    return int((mx[seen] - mn[seen]).max().item()) if bool(seen.any()) else 0
+
+
+def allreduce_sum(t: torch.Tensor):
+    """In-place sum over ranks.  RCCL reduces device tensors directly; the gloo rehearsal stages
+    through the host when the tensor lives on a GPU."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        dist.all_reduce(h)
+        t.copy_(h)
+    else:
+        dist.all_reduce(t)
+    return t
+
+
+class ShardedStereoBASolver:
+    """Landmark-sharded LM: wraps a StereoBASolver built on this rank's observations (all poses, local
+    landmarks, band forced to the global band) and inserts the collectives."""
+
+    def __init__(self, obs_pose, obs_point, meas, n_poses, n_points, K, sigma, prior_pose=None, prior_T=None,
+                 prior_sigmas=None, device="cuda:0"):
+        from .ba import StereoBAProblem, StereoBASolver
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        obs_pose = torch.as_tensor(obs_pose).to(device)
+        obs_point = torch.as_tensor(obs_point).to(device)
+        meas = torch.as_tensor(meas).to(device)
+        band = global_band(obs_pose, obs_point, n_points)
+        op, ol, m, self.lo, self.hi = shard_observations(obs_pose, obs_point, meas, n_points, self.world, self.rank)
+        if self.rank != 0:                      # priors are counted once, on rank 0
+            prior_pose, prior_T, prior_sigmas = None, None, None
+        self.problem = StereoBAProblem(op, ol, m, n_poses, self.hi - self.lo, K, sigma, prior_pose, prior_T,
+                                       prior_sigmas, device=device, band=band)
+        self.solver = _ShardSolver(self.problem, self.world)
+
+    def optimize(self, poses, points, params=None):
+        """poses: full [n_poses,12]; points: full [n_points,3].  Returns (poses, local points slice,
+        report); use gather_points() for the full landmark array."""
+        return self.solver.optimize(poses, points[self.lo:self.hi], params)
+
+    def gather_points(self, local_points: torch.Tensor, n_points: int) -> torch.Tensor:
+        full = torch.zeros((n_points, 3), dtype=torch.float64, device=local_points.device)
+        full[self.lo:self.hi] = local_points
+        return allreduce_sum(full)
+
+
+def _make_shard_solver():
+    from .ba import StereoBASolver
+
+    class _Impl(StereoBASolver):
+        def __init__(self, problem, world):
+            super().__init__(problem)
+            self.world = world
+
+        def error(self, poses, points):
+            super().error(poses, points)
+            allreduce_sum(self.scal[0:1])
+            return float(self.scal[0].item())
+
+        def linearize(self, poses, points):
+            super().linearize(poses, points)
+            allreduce_sum(self.scal[0:1])          # linearised-at-zero error of the whole graph
+
+        def schur(self, lam):
+            super().schur(lam)
+            # THE exchange step: reduced camera system (block band + rhs) summed over landmark shards
+            allreduce_sum(self.Sband)
+            allreduce_sum(self.gs)
+            if self.world > 1:
+                _lib.call("vus_ba_add_diag", _lib.ptr(self.Sband), self.P.n_poses, self.P.band,
+                          -(self.world - 1) * float(lam), _lib.current_stream_ptr())
+
+        def eval_step(self, poses, points):
+            super().eval_step(poses, points)
+            allreduce_sum(self.scal[1:3])
+
+    return _Impl
+
+
+def _ShardSolver(problem, world):
+    return _make_shard_solver()(problem, world)
