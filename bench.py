@@ -84,11 +84,11 @@ def timed_stage_process(fe, images, events):
     _lib.call("vus_orient_rbrief", ptr(images), ptr(fe.blur), n_img, H, W, W, ptr(fe.kp_keys),
               ptr(fe.kp_count), K, ptr(fe.desc), ptr(fe.angle), st)
     ev[3].record()
-    _lib.call("vus_hamming_match", ptr(fe.desc), ptr(fe.kp_keys), ptr(fe.kp_count), K, W, ptr(fe.stereo_q),
+    _lib.call("vus_hamming_match", ptr(fe.desc), ptr(fe.kp_keys), ptr(fe.kp_count), K, H, W, ptr(fe.stereo_q),
               ptr(fe.stereo_t), F, p.stereo_threshold, p.min_disparity, p.max_disparity,
               p.stereo_max_distance, ptr(fe.match_idx), ptr(fe.match_dist), st)
     ev[4].record()
-    _lib.call("vus_hamming_match", ptr(fe.desc), ptr(fe.kp_keys), ptr(fe.kp_count), K, W, ptr(fe.track_q),
+    _lib.call("vus_hamming_match", ptr(fe.desc), ptr(fe.kp_keys), ptr(fe.kp_count), K, H, W, ptr(fe.track_q),
               ptr(fe.track_t), F - 1, -1, 0, 0, p.track_max_distance, ptr(fe.match_idx[fe.max_frames:]),
               ptr(fe.match_dist[fe.max_frames:]), st)
     ev[5].record()

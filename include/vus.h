@@ -84,7 +84,7 @@ int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_img, int H,
  * No gated candidate -> idx -1, dist 512; best distance > max_dist -> idx -1, dist = that distance.
  * idx_out / dist_out: int32 [n_pairs, max_kp]. */
 int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, const int* kp_count,
-                      int max_kp, int W, const int* q_index, const int* t_index, int n_pairs,
+                      int max_kp, int H, int W, const int* q_index, const int* t_index, int n_pairs,
                       int max_dy, int min_disp, int max_disp, int max_dist,
                       int32_t* idx_out, int32_t* dist_out, void* stream);
 

@@ -94,7 +94,7 @@ def orient_rbrief(img, blur, kp_keys, kp_count):
 
 
 def hamming_match(desc, kp_keys, kp_count, W, q_index, t_index, max_dy=-1, min_disp=0, max_disp=0,
-                  max_dist=256):
+                  max_dist=256, H=None):
     desc = np.ascontiguousarray(desc, np.uint64)
     kp_keys = np.ascontiguousarray(kp_keys, np.uint32)
     kp_count = np.ascontiguousarray(kp_count, np.int32)
@@ -104,7 +104,9 @@ def hamming_match(desc, kp_keys, kp_count, W, q_index, t_index, max_dy=-1, min_d
     npairs = q_index.shape[0]
     idx = np.empty((npairs, max_kp), np.int32)
     dist = np.empty((npairs, max_kp), np.int32)
-    _check(lib().vus_hamming_match_cpu(_p(desc), _p(kp_keys), _p(kp_count), max_kp, int(W), _p(q_index),
+    if H is None:   # any bound on the row index will do for the oracle
+        H = int((kp_keys & 0xFFFFFF).max()) // int(W) + 1 if kp_keys.size else 1
+    _check(lib().vus_hamming_match_cpu(_p(desc), _p(kp_keys), _p(kp_count), max_kp, int(H), int(W), _p(q_index),
                                        _p(t_index), npairs, int(max_dy), int(min_disp), int(max_disp),
                                        int(max_dist), _p(idx), _p(dist)), "hamming_match")
     return idx, dist

@@ -205,10 +205,10 @@ int vus_orient_rbrief_cpu(const uint8_t* img, const uint8_t* blur, int n_img, in
 }
 
 int vus_hamming_match_cpu(const uint64_t* desc, const uint32_t* kp_keys, const int* kp_count,
-                          int max_kp, int W, const int* q_index, const int* t_index, int n_pairs,
+                          int max_kp, int H, int W, const int* q_index, const int* t_index, int n_pairs,
                           int max_dy, int min_disp, int max_disp, int max_dist,
                           int32_t* idx_out, int32_t* dist_out) {
-  if (!desc || !kp_keys || !kp_count || !q_index || !t_index || !idx_out || !dist_out || W < 1)
+  if (!desc || !kp_keys || !kp_count || !q_index || !t_index || !idx_out || !dist_out || W < 1 || H < 1)
     return VUS_E_INVALID;
 #pragma omp parallel for schedule(dynamic)
   for (int p = 0; p < n_pairs; ++p) {

@@ -213,7 +213,7 @@ def test_hamming_match_bit_exact(gpu, oracle, gate):
     idx = torch.empty((len(q), K), dtype=torch.int32, device="cuda")
     dist = torch.empty((len(q), K), dtype=torch.int32, device="cuda")
     L.call("vus_hamming_match", _dev(desc.view(np.int64)).data_ptr(), _dev(kp.view(np.int32)).data_ptr(),
-           _dev(kc).data_ptr(), K, W, _dev(q).data_ptr(), _dev(t).data_ptr(), len(q), max_dy, mind, maxd,
+           _dev(kc).data_ptr(), K, H, W, _dev(q).data_ptr(), _dev(t).data_ptr(), len(q), max_dy, mind, maxd,
            maxdist, idx.data_ptr(), dist.data_ptr(), L.current_stream_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(idx.cpu().numpy(), eidx)

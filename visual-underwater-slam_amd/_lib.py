@@ -15,7 +15,7 @@ SIGNATURES = {
     "vus_fast_detect": [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
     "vus_select_topk": [_P, _P, c_int, c_int, c_int, _P, _P, _P],
     "vus_orient_rbrief": [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P],
-    "vus_hamming_match": [_P, _P, _P, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
+    "vus_hamming_match": [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "vus_triangulate": [_P, c_int, _P, _P, _P, _P],
     # bundle adjustment (struct arguments are passed by address)
     "vus_ba_linearize": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],

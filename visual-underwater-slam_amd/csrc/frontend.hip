@@ -10,11 +10,13 @@
 // Design notes (MI355X):
 //  * everything is batched over images: grid.z / grid.y = image, so one launch covers the whole
 //    resident stream and fills the 256 CUs;
-//  * fast_detect stages a 72x40 byte tile (64x32 outputs + 4-pixel halo) in LDS once and derives
-//    score, non-max suppression and the 7x7 smoothing from it: the image is read from HBM once;
-//    the score map never goes to HBM (candidates leave the CU as 4-byte keys);
+//  * fast_detect stages a 144x56 byte tile (128x48 outputs + halo) in LDS once, as dwords, and
+//    derives score, non-max suppression and the 7x7 smoothing from it: the image is read from HBM
+//    once; the score map never goes to HBM (candidates leave the CU as 4-byte keys);
+//  * every thread works on strips of 4 adjacent pixels read with ds_read_b32/b64 and unpacked in
+//    registers (SDWA byte selects): byte-wide LDS reads made the first version LDS-issue bound;
 //  * the score is computed branch-free for every pixel with v_min3/v_max3 sliding windows
-//    (no divergence on corner density);
+//    (no divergence on corner density); the smoothing uses v_dot4_u32_u8 on v_alignbyte windows;
 //  * select_topk is an exact 4x8-bit MSB radix select + LDS bitonic sort, one workgroup per image;
 //  * orient_rbrief uses one 64-lane wave per keypoint: lane-strided disc moments, integer bin
 //    choice, and the descriptor words come straight out of __ballot (lane = test bit);
@@ -25,28 +27,39 @@
 
 namespace {
 
-constexpr int TW = 64;      // output tile width
-constexpr int TH = 32;      // output tile height
-constexpr int HALO = 4;     // 3 (FAST circle / blur taps) + 1 (NMS ring)
-constexpr int SW = TW + 2 * HALO;
-constexpr int SH = TH + 2 * HALO;
-constexpr int SCW = TW + 4;  // score tile row stride (TW+2 used)
+constexpr int TW = 128;                 // output tile width  (1280 = 10 tiles)
+constexpr int TH = 48;                  // output tile height (720 = 15 tiles)
 constexpr int NTHREADS = 256;
+// LDS images are arrays of dwords = 4 horizontally adjacent pixels ("strips"); every phase reads
+// ds_read_b32/b64 and unpacks bytes in registers (byte-wide LDS reads cost ~3x the LDS cycles).
+constexpr int IMG_ROWS = TH + 8;        // image rows  y0-4 .. y0+TH+3
+constexpr int IMG_DW = (TW + 16) / 4;   // image cols  x0-8 .. x0+TW+7
+constexpr int SC_ROWS = TH + 2;         // score rows  y0-1 .. y0+TH
+constexpr int SC_DW = (TW + 8) / 4;     // score cols  x0-4 .. x0+TW+3
+constexpr int H_ROWS = TH + 6;          // horizontally smoothed rows y0-3 .. y0+TH+2
+constexpr int H_DW = TW / 2;            // two u16 per dword
+constexpr int STRIPS = TW / 4;
 
 __device__ __forceinline__ int clampi(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 __device__ __forceinline__ int min3i(int a, int b, int c) { return min(min(a, b), c); }
 __device__ __forceinline__ int max3i(int a, int b, int c) { return max(max(a, b), c); }
+__device__ __forceinline__ int byte_of(uint32_t w, int i) { return (int)((w >> (8 * i)) & 0xFFu); }
 
-// FAST-9/16 score of the pixel at c (LDS), rows `stride` bytes apart.  Sliding-window min / max of
-// the 16 circle differences over every arc of 9:  w3[k] = op(d[k..k+2]),  w9[k] = op(w3[k],
-// w3[k+3], w3[k+6]).  Bright arcs need min(d) large, dark arcs need max(d) small (very negative).
-__device__ __forceinline__ int fast_score_at(const uint8_t* c, int stride) {
+// FAST-9/16 score of pixel e (0..3) of a strip.  r[row][j]: 7 image rows x 3 dwords; the strip's
+// pixels are bytes 4..7 of each 12-byte row window.  Sliding-window min / max of the 16 circle
+// differences over every arc of 9:  w3[k] = op(d[k..k+2]),  w9[k] = op(w3[k], w3[k+3], w3[k+6]).
+// Bright arcs need min(d) large, dark arcs need max(d) small (very negative).
+template <int E>
+__device__ __forceinline__ int fast_score_strip(const uint32_t (&r)[7][3]) {
   constexpr int DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
   constexpr int DY[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
-  const int p = c[0];
+  const int p = byte_of(r[3][1], E);
   int d[16];
 #pragma unroll
-  for (int k = 0; k < 16; ++k) d[k] = (int)c[DY[k] * stride + DX[k]] - p;
+  for (int k = 0; k < 16; ++k) {
+    const int pos = 4 + E + DX[k];
+    d[k] = byte_of(r[3 + DY[k]][pos >> 2], pos & 3) - p;
+  }
   int mn3[16], mx3[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) {
@@ -62,92 +75,164 @@ __device__ __forceinline__ int fast_score_at(const uint8_t* c, int stride) {
   return max(best_bright, -best_dark) - 1;
 }
 
+template <int E>
+__device__ __forceinline__ bool nms_keep(const uint32_t (&c)[3][3]) {
+  // pixel E of the strip = byte 4+E of the 12-byte windows; strict maximum of its 8 neighbours
+  const int s = byte_of(c[1][1], E);
+  int m = 0;
+#pragma unroll
+  for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      if (dy == 1 && dx == 0) continue;
+      const int pos = 4 + E + dx;
+      m = max(m, byte_of(c[dy][pos >> 2], pos & 3));
+    }
+  return s > m;
+}
+
 template <bool WRITE_SCORE, bool DETECT, bool BLUR>
 __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
     const uint8_t* __restrict__ img, int H, int W, int pitch, int thr, int border,
     uint8_t* __restrict__ score_out, uint8_t* __restrict__ blur_out,
     uint32_t* __restrict__ cand_keys, int cand_cap, int* __restrict__ cand_count) {
-  __shared__ uint8_t s_img[SH * SW];
-  __shared__ uint8_t s_score[(TH + 2) * SCW];
-  __shared__ uint16_t s_h[(TH + 6) * TW];
-  __shared__ uint32_t s_keys[TH * TW / 4];
+  __shared__ uint32_t s_img[IMG_ROWS * IMG_DW];
+  __shared__ uint32_t s_score[(WRITE_SCORE || DETECT) ? SC_ROWS * SC_DW : 1];
+  __shared__ uint32_t s_h[BLUR ? H_ROWS * H_DW : 2];
   __shared__ int s_cnt, s_base;
+  // the candidate list reuses the image tile, which is dead after the second barrier
+  static_assert(IMG_ROWS * IMG_DW >= TW * TH / 4, "candidate list must fit in the image tile");
+  uint32_t* const s_keys = s_img;
 
   const int tid = threadIdx.x;
   const int n = blockIdx.z;
   const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const uint8_t* im = img + (size_t)n * H * pitch;
 
-  // stage the tile; out-of-image pixels replicate the border (what the smoothing wants; FAST never
-  // produces a score within 3 pixels of the edge, so it does not care)
-  for (int idx = tid; idx < SH * SW; idx += NTHREADS) {
-    int ly = idx / SW, lx = idx - ly * SW;
-    int gy = clampi(y0 - HALO + ly, 0, H - 1), gx = clampi(x0 - HALO + lx, 0, W - 1);
-    s_img[idx] = im[(size_t)gy * pitch + gx];
+  // stage the tile as dwords; out-of-image pixels replicate the border (what the smoothing wants;
+  // FAST never produces a score within 3 pixels of the edge, so it does not care)
+  const bool al_in = ((reinterpret_cast<uintptr_t>(im) | (uintptr_t)pitch) & 3u) == 0;
+  for (int idx = tid; idx < IMG_ROWS * IMG_DW; idx += NTHREADS) {
+    const int row = idx / IMG_DW, col = idx - row * IMG_DW;
+    const int gy = clampi(y0 - 4 + row, 0, H - 1), gx = x0 - 8 + 4 * col;
+    const uint8_t* rp = im + (size_t)gy * pitch;
+    uint32_t v;
+    if (al_in && gx >= 0 && gx + 3 < W) {
+      v = *reinterpret_cast<const uint32_t*>(rp + gx);
+    } else {
+      v = (uint32_t)rp[clampi(gx, 0, W - 1)] | ((uint32_t)rp[clampi(gx + 1, 0, W - 1)] << 8) |
+          ((uint32_t)rp[clampi(gx + 2, 0, W - 1)] << 16) | ((uint32_t)rp[clampi(gx + 3, 0, W - 1)] << 24);
+    }
+    s_img[idx] = v;
   }
   if (tid == 0) s_cnt = 0;
   __syncthreads();
 
   if (WRITE_SCORE || DETECT) {
-    // score on the tile plus a 1-pixel ring (needed by the 3x3 non-max suppression)
-    for (int idx = tid; idx < (TH + 2) * (TW + 2); idx += NTHREADS) {
-      int ly = idx / (TW + 2), lx = idx - ly * (TW + 2);
-      int gy = y0 - 1 + ly, gx = x0 - 1 + lx;
-      int s = 0;
-      if (gy >= 3 && gy < H - 3 && gx >= 3 && gx < W - 3) {
-        int sc = fast_score_at(&s_img[(ly + 3) * SW + (lx + 3)], SW);
-        s = sc >= thr ? sc : 0;
+    // scores of the tile plus a ring (the 3x3 non-max suppression needs 1 pixel), one strip of 4 per item
+    for (int idx = tid; idx < SC_ROWS * SC_DW; idx += NTHREADS) {
+      const int sr = idx / SC_DW, ss = idx - sr * SC_DW;
+      const int gy = y0 - 1 + sr, gx = x0 - 4 + 4 * ss;
+      uint32_t packed = 0;
+      if (gy >= 3 && gy < H - 3 && gx + 3 >= 3 && gx < W - 3) {
+        uint32_t r[7][3];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) r[k][j] = s_img[(sr + k) * IMG_DW + ss + j];
+        int sc[4] = {fast_score_strip<0>(r), fast_score_strip<1>(r), fast_score_strip<2>(r), fast_score_strip<3>(r)};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool ok = sc[e] >= thr && gx + e >= 3 && gx + e < W - 3;
+          packed |= ok ? ((uint32_t)sc[e] << (8 * e)) : 0u;
+        }
       }
-      s_score[ly * SCW + lx] = (uint8_t)s;
+      s_score[idx] = packed;
     }
   }
   if (BLUR) {
-    constexpr int BW[7] = {18, 33, 49, 56, 49, 33, 18};
-    // horizontal pass over rows y0-3 .. y0+TH+2
-    for (int idx = tid; idx < (TH + 6) * TW; idx += NTHREADS) {
-      int ly = idx / TW, lx = idx - ly * TW;
-      const uint8_t* r = &s_img[(ly + 1) * SW + (lx + 1)];
-      int acc = 0;
-#pragma unroll
-      for (int k = 0; k < 7; ++k) acc += BW[k] * (int)r[k];
-      s_h[idx] = (uint16_t)acc;
+    // horizontal 7-tap pass: 4 outputs per item from 3 dwords, two v_dot4_u32_u8 per output
+    constexpr uint32_t W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
+    constexpr uint32_t W456 = 49u | (33u << 8) | (18u << 16);
+    for (int idx = tid; idx < H_ROWS * STRIPS; idx += NTHREADS) {
+      const int hr = idx / STRIPS, hs = idx - hr * STRIPS;
+      const uint32_t* rp = &s_img[(hr + 1) * IMG_DW + hs + 1];
+      const uint32_t a = rp[0], b = rp[1], c = rp[2];
+      // output e covers bytes (1+e)..(7+e) of the 12-byte window {a,b,c}
+      const uint32_t o0 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 1), W0123, 0u, false) +
+                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, b, 1), W456, 0u, false);
+      const uint32_t o1 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 2), W0123, 0u, false) +
+                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, b, 2), W456, 0u, false);
+      const uint32_t o2 = __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(b, a, 3), W0123, 0u, false) +
+                          __builtin_amdgcn_udot4(__builtin_amdgcn_alignbyte(c, b, 3), W456, 0u, false);
+      const uint32_t o3 = __builtin_amdgcn_udot4(b, W0123, 0u, false) + __builtin_amdgcn_udot4(c, W456, 0u, false);
+      uint2 out = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));
+      *reinterpret_cast<uint2*>(&s_h[hr * H_DW + 2 * hs]) = out;
     }
   }
   __syncthreads();
 
   if (WRITE_SCORE) {
-    for (int idx = tid; idx < TH * TW; idx += NTHREADS) {
-      int ly = idx / TW, lx = idx - ly * TW;
-      int gy = y0 + ly, gx = x0 + lx;
-      if (gy < H && gx < W) score_out[((size_t)n * H + gy) * W + gx] = s_score[(ly + 1) * SCW + lx + 1];
+    for (int idx = tid; idx < TH * STRIPS; idx += NTHREADS) {
+      const int ly = idx / STRIPS, ls = idx - ly * STRIPS;
+      const int gy = y0 + ly, gx = x0 + 4 * ls;
+      const uint32_t v = s_score[(ly + 1) * SC_DW + ls + 1];
+      if (gy < H) {
+        uint8_t* o = score_out + ((size_t)n * H + gy) * W + gx;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (gx + e < W) o[e] = (uint8_t)(v >> (8 * e));
+      }
     }
   }
   if (BLUR) {
     constexpr int BW[7] = {18, 33, 49, 56, 49, 33, 18};
-    for (int idx = tid; idx < TH * TW; idx += NTHREADS) {
-      int ly = idx / TW, lx = idx - ly * TW;
-      int gy = y0 + ly, gx = x0 + lx;
-      int acc = 0;
+    const bool al_out = ((reinterpret_cast<uintptr_t>(blur_out) | (uintptr_t)W) & 3u) == 0;
+    for (int idx = tid; idx < TH * STRIPS; idx += NTHREADS) {
+      const int ly = idx / STRIPS, ls = idx - ly * STRIPS;
+      const int gy = y0 + ly, gx = x0 + 4 * ls;
+      uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-      for (int k = 0; k < 7; ++k) acc += BW[k] * (int)s_h[(ly + k) * TW + lx];
-      if (gy < H && gx < W) blur_out[((size_t)n * H + gy) * W + gx] = (uint8_t)((acc + 32768) >> 16);
+      for (int k = 0; k < 7; ++k) {
+        const uint2 h = *reinterpret_cast<const uint2*>(&s_h[(ly + k) * H_DW + 2 * ls]);
+        a0 += (uint32_t)BW[k] * (h.x & 0xFFFFu);
+        a1 += (uint32_t)BW[k] * (h.x >> 16);
+        a2 += (uint32_t)BW[k] * (h.y & 0xFFFFu);
+        a3 += (uint32_t)BW[k] * (h.y >> 16);
+      }
+      const uint32_t v = ((a0 + 32768u) >> 16) | (((a1 + 32768u) >> 16) << 8) | (((a2 + 32768u) >> 16) << 16) |
+                         (((a3 + 32768u) >> 16) << 24);
+      if (gy < H) {
+        uint8_t* o = blur_out + ((size_t)n * H + gy) * W + gx;
+        if (al_out && gx + 3 < W) {
+          *reinterpret_cast<uint32_t*>(o) = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gx + e < W) o[e] = (uint8_t)(v >> (8 * e));
+        }
+      }
     }
   }
   if (DETECT) {
-    for (int idx = tid; idx < TH * TW; idx += NTHREADS) {
-      int ly = idx / TW, lx = idx - ly * TW;
-      int gy = y0 + ly, gx = x0 + lx;
-      const uint8_t* c = &s_score[(ly + 1) * SCW + lx + 1];
-      int s = c[0];
-      bool keep = s > 0 && gy >= border && gy < H - border && gx >= border && gx < W - border;
-      if (keep) {
-        int m = max(max3i(c[-SCW - 1], c[-SCW], c[-SCW + 1]), max(c[-1], c[1]));
-        m = max(m, max3i(c[SCW - 1], c[SCW], c[SCW + 1]));
-        keep = s > m;  // strict maximum of its 8 neighbours
-      }
-      if (keep) {
-        int p = atomicAdd(&s_cnt, 1);
-        s_keys[p] = ((uint32_t)(255 - s) << VUS_KEY_POS_BITS) | (uint32_t)(gy * W + gx);
+    for (int idx = tid; idx < TH * STRIPS; idx += NTHREADS) {
+      const int ly = idx / STRIPS, ls = idx - ly * STRIPS;
+      const int gy = y0 + ly, gx = x0 + 4 * ls;
+      const uint32_t centre = s_score[(ly + 1) * SC_DW + ls + 1];
+      if (centre == 0u || gy < border || gy >= H - border) continue;
+      uint32_t c[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[k][j] = s_score[(ly + k) * SC_DW + ls + j];
+      const bool keep[4] = {nms_keep<0>(c), nms_keep<1>(c), nms_keep<2>(c), nms_keep<3>(c)};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int s = byte_of(centre, e);
+        if (s > 0 && keep[e] && gx + e >= border && gx + e < W - border) {
+          const int p = atomicAdd(&s_cnt, 1);
+          s_keys[p] = ((uint32_t)(255 - s) << VUS_KEY_POS_BITS) | (uint32_t)(gy * W + gx + e);
+        }
       }
     }
     __syncthreads();
@@ -240,62 +325,122 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // One wave per keypoint: orientation bin + 256-bit rotated BRIEF.
+// Each wave stages the keypoint's two patches in LDS with row-contiguous dword loads (31 rows of the
+// image for the centroid disc, 37 rows of the smoothed image for the tests), then gathers from LDS.
+constexpr int OR_R = 15;                    // disc radius
+constexpr int OR_ROWS = 2 * OR_R + 1;       // 31
+constexpr int OR_DW = 9;                    // 36 bytes cover x-15..x+15 from an aligned start
+constexpr int BR_R = VUS_RBRIEF_REACH;      // 18
+constexpr int BR_ROWS = 2 * BR_R + 1;       // 37
+constexpr int BR_DW = 10;                   // 40 bytes cover x-18..x+18 from an aligned start
+constexpr int OR_KP_PER_WAVE = 4;           // keypoints handled sequentially by one wave
+constexpr int OR_DISC_ITERS = (VUS_DISC_N + 63) / 64;
+
+__device__ __forceinline__ void stage_patch(const uint8_t* __restrict__ src, int H, int W, int pitch, int y, int x,
+                                            int radius, int rows, int dw, uint32_t* __restrict__ dst, int lane,
+                                            bool aligned) {
+  const int xa = (x - radius) & ~3;   // aligned start column (floor)
+  const bool inside = aligned && y - radius >= 0 && y + radius < H && xa >= 0 && xa + 4 * dw <= W;
+  if (inside) {   // wave-uniform
+    for (int t = lane; t < rows * dw; t += 64) {
+      const int r = t / dw, c = t - r * dw;
+      dst[t] = *reinterpret_cast<const uint32_t*>(src + (size_t)(y - radius + r) * pitch + xa + 4 * c);
+    }
+  } else {        // replicate-clamped, byte by byte (keypoints near the image edge)
+    for (int t = lane; t < rows * dw; t += 64) {
+      const int r = t / dw, c = t - r * dw;
+      const uint8_t* rp = src + (size_t)clampi(y - radius + r, 0, H - 1) * pitch;
+      const int gx = xa + 4 * c;
+      dst[t] = (uint32_t)rp[clampi(gx, 0, W - 1)] | ((uint32_t)rp[clampi(gx + 1, 0, W - 1)] << 8) |
+               ((uint32_t)rp[clampi(gx + 2, 0, W - 1)] << 16) | ((uint32_t)rp[clampi(gx + 3, 0, W - 1)] << 24);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void orient_rbrief_kernel(
     const uint8_t* __restrict__ img, const uint8_t* __restrict__ blur, int H, int W, int pitch,
     const uint32_t* __restrict__ kp_keys, const int* __restrict__ kp_count, int max_kp,
     uint64_t* __restrict__ desc_out, uint8_t* __restrict__ angle_out) {
+  __shared__ uint32_t s_raw[4][OR_ROWS * OR_DW];
+  __shared__ uint32_t s_blur[4][BR_ROWS * BR_DW];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int n = blockIdx.y;
-  const int i = blockIdx.x * 4 + wave;
-  if (i >= max_kp) return;
-  uint64_t* d = desc_out + ((size_t)n * max_kp + i) * 4;
-  if (i >= kp_count[n]) {  // unused slot: defined contents
-    if (lane < 4) d[lane] = 0;
-    if (lane == 0) angle_out[(size_t)n * max_kp + i] = 0;
-    return;
-  }
-  const uint32_t pos = kp_keys[(size_t)n * max_kp + i] & VUS_KEY_POS_MASK;
-  const int y = (int)(pos / (uint32_t)W), x = (int)(pos - (uint32_t)y * (uint32_t)W);
   const uint8_t* im = img + (size_t)n * H * pitch;
   const uint8_t* bl = blur + (size_t)n * H * W;
-
-  // intensity centroid: each lane sums a strided share of the 749 disc pixels
-  int m10 = 0, m01 = 0;
-  for (int k = lane; k < VUS_DISC_N; k += 64) {
-    int dx = VUS_DISC_DX[k], dy = VUS_DISC_DY[k];
-    int v = im[(size_t)clampi(y + dy, 0, H - 1) * pitch + clampi(x + dx, 0, W - 1)];
-    m10 += dx * v;
-    m01 += dy * v;
-  }
+  const bool al_img = ((reinterpret_cast<uintptr_t>(im) | (uintptr_t)pitch) & 3u) == 0;
+  const bool al_blur = ((reinterpret_cast<uintptr_t>(bl) | (uintptr_t)W) & 3u) == 0;
+  const int count = kp_count[n];
+  const uint8_t* raw8 = reinterpret_cast<const uint8_t*>(s_raw[wave]);
+  const uint8_t* blur8 = reinterpret_cast<const uint8_t*>(s_blur[wave]);
+  // this lane's share of the disc: byte offset inside the staged patch and the moment weights
+  int disc_off[OR_DISC_ITERS], disc_dx[OR_DISC_ITERS], disc_dy[OR_DISC_ITERS];
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    m10 += __shfl_xor(m10, o);
-    m01 += __shfl_xor(m01, o);
+  for (int k = 0; k < OR_DISC_ITERS; ++k) {
+    const int e = lane + 64 * k;
+    const bool v = e < VUS_DISC_N;
+    disc_dx[k] = v ? VUS_DISC_DX[e] : 0;
+    disc_dy[k] = v ? VUS_DISC_DY[e] : 0;
+    disc_off[k] = v ? (disc_dy[k] + OR_R) * (4 * OR_DW) + disc_dx[k] + OR_R : 0;
   }
-  // nearest bin direction = largest projection, first maximum wins (integer, exact)
-  long long pr = lane < VUS_N_ANGLE_BINS
-                     ? (long long)m10 * VUS_ANGLE_COS[lane] + (long long)m01 * VUS_ANGLE_SIN[lane]
-                     : (long long)(-0x7FFFFFFFFFFFFFFFll - 1);
-  int bin = lane;
+  for (int it = 0; it < OR_KP_PER_WAVE; ++it) {   // uniform trip count: barriers are legal
+    const int i = (blockIdx.x * OR_KP_PER_WAVE + it) * 4 + wave;
+    const bool live = i < count && i < max_kp;
+    int y = 0, x = 0;
+    if (live) {
+      const uint32_t pos = kp_keys[(size_t)n * max_kp + i] & VUS_KEY_POS_MASK;
+      y = (int)(pos / (uint32_t)W);
+      x = (int)(pos - (uint32_t)y * (uint32_t)W);
+      stage_patch(im, H, W, pitch, y, x, OR_R, OR_ROWS, OR_DW, s_raw[wave], lane, al_img);
+      stage_patch(bl, H, W, W, y, x, BR_R, BR_ROWS, BR_DW, s_blur[wave], lane, al_blur);
+    }
+    __syncthreads();
+    if (live) {
+      const int sh_raw = (x - OR_R) & 3, sh_blur = (x - BR_R) & 3;   // patch column of x-radius
+      int m10 = 0, m01 = 0;
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    long long opr = __shfl_xor(pr, o);
-    int obin = __shfl_xor(bin, o);
-    if (opr > pr || (opr == pr && obin < bin)) { pr = opr; bin = obin; }
-  }
-  const char4* pat = reinterpret_cast<const char4*>(VUS_RBRIEF_ROT) + (size_t)bin * 256;
-  uint64_t word[4];
+      for (int k = 0; k < OR_DISC_ITERS; ++k) {
+        const int v = (lane + 64 * k < VUS_DISC_N) ? raw8[disc_off[k] + sh_raw] : 0;
+        m10 += disc_dx[k] * v;
+        m01 += disc_dy[k] * v;
+      }
 #pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    char4 t = pat[w * 64 + lane];
-    int a = bl[(size_t)clampi(y + t.y, 0, H - 1) * W + clampi(x + t.x, 0, W - 1)];
-    int b = bl[(size_t)clampi(y + t.w, 0, H - 1) * W + clampi(x + t.z, 0, W - 1)];
-    word[w] = __ballot(a < b);  // lane l supplies bit l of word w
-  }
-  if (lane == 0) {
-    d[0] = word[0]; d[1] = word[1]; d[2] = word[2]; d[3] = word[3];
-    angle_out[(size_t)n * max_kp + i] = (uint8_t)bin;
+      for (int o = 32; o > 0; o >>= 1) {
+        m10 += __shfl_xor(m10, o);
+        m01 += __shfl_xor(m01, o);
+      }
+      // nearest bin direction = largest projection, first maximum wins (integer, exact)
+      long long pr = lane < VUS_N_ANGLE_BINS
+                         ? (long long)m10 * VUS_ANGLE_COS[lane] + (long long)m01 * VUS_ANGLE_SIN[lane]
+                         : (long long)(-0x7FFFFFFFFFFFFFFFll - 1);
+      int bin = lane;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        long long opr = __shfl_xor(pr, o);
+        int obin = __shfl_xor(bin, o);
+        if (opr > pr || (opr == pr && obin < bin)) { pr = opr; bin = obin; }
+      }
+      const char4* pat = reinterpret_cast<const char4*>(VUS_RBRIEF_ROT) + (size_t)bin * 256;
+      const uint8_t* c = blur8 + BR_R * (4 * BR_DW) + BR_R + sh_blur;   // the keypoint inside the patch
+      uint64_t word[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const char4 t = pat[w * 64 + lane];
+        const int a = c[t.y * (4 * BR_DW) + t.x];
+        const int b = c[t.w * (4 * BR_DW) + t.z];
+        word[w] = __ballot(a < b);  // lane l supplies bit l of word w
+      }
+      if (lane == 0) {
+        uint64_t* d = desc_out + ((size_t)n * max_kp + i) * 4;
+        d[0] = word[0]; d[1] = word[1]; d[2] = word[2]; d[3] = word[3];
+        angle_out[(size_t)n * max_kp + i] = (uint8_t)bin;
+      }
+    } else if (i < max_kp) {   // unused slot: defined contents
+      uint64_t* d = desc_out + ((size_t)n * max_kp + i) * 4;
+      if (lane < 4) d[lane] = 0;
+      if (lane == 0) angle_out[(size_t)n * max_kp + i] = 0;
+    }
+    __syncthreads();
   }
 }
 
@@ -349,6 +494,88 @@ __global__ __launch_bounds__(256) void hamming_match_kernel(
           ok = dy <= max_dy && dy >= -max_dy && dx >= min_disp && dx <= max_disp;
         }
         if (ok && dist < best) { best = dist; bidx = t0 + j; }
+      }
+    }
+  }
+  if (i < max_kp) {
+    if (bidx < 0) best = 512;
+    else if (best > max_dist) bidx = -1;
+    idx_out[(size_t)p * max_kp + i] = bidx;
+    dist_out[(size_t)p * max_kp + i] = best;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-gated Hamming (stereo): only train keypoints within max_dy rows of the query can match, so the
+// train set is bucketed by image row in LDS (counting sort) and each query lane visits the ~30
+// keypoints of its 2*max_dy+1 rows instead of all 2000.  Ties are broken on the train index
+// explicitly, so the visiting order does not matter and the result equals the brute-force scan.
+__global__ __launch_bounds__(256) void hamming_match_rows_kernel(
+    const uint64_t* __restrict__ desc, const uint32_t* __restrict__ kp_keys,
+    const int* __restrict__ kp_count, int max_kp, int W, int Hrows, const int* __restrict__ q_index,
+    const int* __restrict__ t_index, int max_dy, int min_disp, int max_disp, int max_dist,
+    int32_t* __restrict__ idx_out, int32_t* __restrict__ dist_out) {
+  extern __shared__ int s_dyn[];
+  int* s_start = s_dyn;                         // [Hrows + 1] first slot of every row
+  int* s_cursor = s_dyn + (Hrows + 1);          // [Hrows]
+  int* s_list = s_cursor + Hrows;               // [max_kp] train indices grouped by row
+  int* s_xy = s_list + max_kp;                  // [max_kp] (y << 16) | x per train index
+  __shared__ int s_wsum[4];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.y;
+  const int qi = q_index[p], ti = t_index[p];
+  const int i = blockIdx.x * 256 + tid;
+  const int nq = min(kp_count[qi], max_kp), nt = min(kp_count[ti], max_kp);
+  const uint32_t* kt = kp_keys + (size_t)ti * max_kp;
+  for (int r = tid; r <= Hrows; r += 256) s_start[r] = 0;
+  __syncthreads();
+  for (int j = tid; j < nt; j += 256) {
+    const uint32_t pt = kt[j] & VUS_KEY_POS_MASK;
+    const int yt = min((int)(pt / (uint32_t)W), Hrows - 1);
+    s_xy[j] = (yt << 16) | (int)(pt - (uint32_t)(pt / (uint32_t)W) * (uint32_t)W);
+    atomicAdd(&s_start[yt + 1], 1);
+  }
+  __syncthreads();
+  // inclusive scan of s_start[1..Hrows] (counts) -> row starts; 256 threads, chunked
+  {
+    const int per = (Hrows + 255) / 256;
+    const int b = 1 + tid * per, e = min(Hrows + 1, b + per);
+    int sum = 0;
+    for (int r = b; r < e; ++r) sum += s_start[r];
+    int incl = sum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int v = __shfl_up(incl, o);
+      if ((tid & 63) >= o) incl += v;
+    }
+    if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+    __syncthreads();
+    int base = incl - sum;
+    for (int w = 0; w < (tid >> 6); ++w) base += s_wsum[w];
+    for (int r = b; r < e; ++r) { base += s_start[r]; s_start[r] = base; }
+  }
+  __syncthreads();
+  for (int r = tid; r < Hrows; r += 256) s_cursor[r] = s_start[r];
+  __syncthreads();
+  for (int j = tid; j < nt; j += 256) s_list[atomicAdd(&s_cursor[s_xy[j] >> 16], 1)] = j;
+  __syncthreads();
+
+  int best = 1 << 20, bidx = -1;
+  if (i < nq) {
+    const uint64_t* dq = desc + ((size_t)qi * max_kp + i) * 4;
+    const uint64_t q0 = dq[0], q1 = dq[1], q2 = dq[2], q3 = dq[3];
+    const uint32_t pq = kp_keys[(size_t)qi * max_kp + i] & VUS_KEY_POS_MASK;
+    const int yq = (int)(pq / (uint32_t)W), xq = (int)(pq - (uint32_t)yq * (uint32_t)W);
+    const int r0 = max(0, yq - max_dy), r1 = min(Hrows - 1, yq + max_dy);
+    const uint64_t* dt = desc + (size_t)ti * max_kp * 4;
+    if (r0 <= r1) {
+      for (int c = s_start[r0]; c < s_start[r1 + 1]; ++c) {
+        const int j = s_list[c];
+        const int dx = xq - (s_xy[j] & 0xFFFF);
+        if (dx < min_disp || dx > max_disp) continue;
+        const uint64_t* d = dt + (size_t)j * 4;
+        const int dist = __popcll(q0 ^ d[0]) + __popcll(q1 ^ d[1]) + __popcll(q2 ^ d[2]) + __popcll(q3 ^ d[3]);
+        if (dist < best || (dist == best && j < bidx)) { best = dist; bidx = j; }
       }
     }
   }
@@ -462,7 +689,7 @@ extern "C" int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_
   VUS_REQUIRE(blur && kp_keys && kp_count && desc_out && angle_out, "null buffer");
   VUS_REQUIRE(max_kp >= 1, "max_kp=%d", max_kp);
   if (n_img == 0) return VUS_OK;
-  dim3 grid((max_kp + 3) / 4, n_img);
+  dim3 grid((max_kp + 4 * OR_KP_PER_WAVE - 1) / (4 * OR_KP_PER_WAVE), n_img);
   orient_rbrief_kernel<<<grid, 256, 0, vus::as_stream(stream)>>>(img, blur, H, W, pitch, kp_keys, kp_count,
                                                               max_kp, desc_out, angle_out);
   VUS_CHECK_LAUNCH("orient_rbrief");
@@ -470,17 +697,28 @@ extern "C" int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_
 }
 
 extern "C" int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, const int* kp_count,
-                                 int max_kp, int W, const int* q_index, const int* t_index, int n_pairs,
+                                 int max_kp, int H, int W, const int* q_index, const int* t_index, int n_pairs,
                                  int max_dy, int min_disp, int max_disp, int max_dist,
                                  int32_t* idx_out, int32_t* dist_out, void* stream) {
   VUS_REQUIRE(desc && kp_keys && kp_count && q_index && t_index && idx_out && dist_out, "null buffer");
-  VUS_REQUIRE(max_kp >= 1 && W >= 1 && W < 65536, "max_kp=%d W=%d", max_kp, W);
+  VUS_REQUIRE(max_kp >= 1 && W >= 1 && W < 65536 && H >= 1 && H < 65536, "max_kp=%d H=%d W=%d", max_kp, H, W);
   VUS_REQUIRE(n_pairs >= 0 && n_pairs <= 65535, "n_pairs=%d out of range [0, 65535]", n_pairs);
   if (n_pairs == 0) return VUS_OK;
   dim3 grid((max_kp + 255) / 256, n_pairs);
-  hamming_match_kernel<<<grid, 256, 0, vus::as_stream(stream)>>>(desc, kp_keys, kp_count, max_kp, W, q_index,
-                                                              t_index, max_dy, min_disp, max_disp, max_dist,
-                                                              idx_out, dist_out);
+  const int h_rows = H;   // the gated kernel buckets the train keypoints by image row
+  const size_t lds = sizeof(int) * ((size_t)2 * h_rows + 1 + 2 * (size_t)max_kp);
+  if (max_dy >= 0 && h_rows <= 16384 && lds <= 96 * 1024) {
+    if (lds > 48 * 1024)
+      VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(hamming_match_rows_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hamming_match_rows_kernel<<<grid, 256, lds, vus::as_stream(stream)>>>(
+        desc, kp_keys, kp_count, max_kp, W, h_rows, q_index, t_index, max_dy, min_disp, max_disp, max_dist, idx_out,
+        dist_out);
+  } else {
+    hamming_match_kernel<<<grid, 256, 0, vus::as_stream(stream)>>>(desc, kp_keys, kp_count, max_kp, W, q_index,
+                                                                t_index, max_dy, min_disp, max_disp, max_dist,
+                                                                idx_out, dist_out);
+  }
   VUS_CHECK_LAUNCH("hamming_match");
   return VUS_OK;
 }

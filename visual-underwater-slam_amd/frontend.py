@@ -121,11 +121,11 @@ class StereoOrbFrontend:
                   ptr(self.kp_keys), ptr(self.kp_count), st)
         _lib.call("vus_orient_rbrief", ptr(images), ptr(self.blur), n_img, H, W, W, ptr(self.kp_keys),
                   ptr(self.kp_count), K, ptr(self.desc), ptr(self.angle), st)
-        _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, W,
+        _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, H, W,
                   ptr(self.stereo_q), ptr(self.stereo_t), F, p.stereo_threshold, p.min_disparity,
                   p.max_disparity, p.stereo_max_distance, ptr(self.match_idx), ptr(self.match_dist), st)
         if F > 1:
-            _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, W,
+            _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, H, W,
                       ptr(self.track_q), ptr(self.track_t), F - 1, -1, 0, 0, p.track_max_distance,
                       ptr(self.match_idx[self.max_frames:]), ptr(self.match_dist[self.max_frames:]), st)
         if check:
