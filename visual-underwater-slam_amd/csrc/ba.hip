@@ -17,7 +17,8 @@
 //   vinv, ymul   thread / point, thread / obs   (V + lambda I)^-1,  Y = W Vinv
 //   schur_init / schur_blocks / schur_rhs       S = Hpp + lambda I - sum Y W^T (wave per 6x6 block,
 //                60 lanes = 5 pair slices x 12 three-element strips), gs = gp - sum Y gl
-//   chol_panel / chol_trsm / chol_update / chol_backsolve   block-band Cholesky, 8-pose panels
+//   chol_panel / chol_trsm / chol_update / chol_backsolve   block-band Cholesky, 8-pose panels;
+//                the trailing SYRK update runs on v_mfma_f64_16x16x4_f64
 //   backsub      wave / point      dl = -Vinv (gl + sum W^T dp)
 //   retract, eval_points, error_points, reduce_partials
 #include "vus_common.h"
@@ -437,6 +438,15 @@ __global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const d
 // ---------------------------------------------------------------------------------------------
 // block-band Cholesky, right-looking, panels of PB poses (NB = 6 PB scalar columns).
 // Sband entry (i, s) is the 6x6 block (i, i - s), s in [0, band].
+//
+// Per panel three launches:
+//   chol_panel   ONE wave; lane R keeps row R of the 48x48 diagonal block in registers (the
+//                right-hand side rides along as row 48), 48 fully unrolled column steps, the
+//                pivot column is broadcast through a 49-entry LDS vector; no divides in the loop
+//                (v_rsq_f64 + two Newton steps);
+//   chol_trsm    one scalar row of the window per lane, x[48] in registers, L_D broadcast from LDS;
+//   chol_update  SYRK of the window, 96x96 tiles, v_mfma_f64_16x16x4_f64 (K = 48): the only
+//                GEMM-shaped part of the path and where the factorisation's flops are.
 constexpr int PB = 8;
 constexpr int NB = 6 * PB;
 constexpr int LDD = NB + 1;
@@ -444,189 +454,267 @@ constexpr int LDD = NB + 1;
 __device__ __forceinline__ double* blk_ptr(double* Sb, int band, int i, int k) {
   return Sb + 36 * ((size_t)i * (band + 1) + (i - k));
 }
+__device__ __forceinline__ const double* blk_ptr(const double* Sb, int band, int i, int k) {
+  return Sb + 36 * ((size_t)i * (band + 1) + (i - k));
+}
 
-// Factor the diagonal panel block (lower) in LDS, with the right-hand side riding along as an extra
-// row (so the forward substitution L y = -gs is done by the same row operations).
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
-                                                         double* __restrict__ yv, int* __restrict__ status) {
-  __shared__ double D[(NB + 1) * LDD];
-  const int tid = threadIdx.x;
+__device__ __forceinline__ double bcast_lane(double v, int src_lane) {   // src_lane wave-uniform
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ double rsqrt_newton(double d) {
+  double r = __builtin_amdgcn_rsq(d);
+  r = r * (1.5 - 0.5 * d * r * r);
+  r = r * (1.5 - 0.5 * d * r * r);
+  return r;
+}
+
+__global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
+                                                        double* __restrict__ yv, int* __restrict__ status) {
+  __shared__ double s_l[2][64];
+  const int lane = threadIdx.x;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
-  for (int t = tid; t < (nb + 1) * nb; t += 256) {
-    const int R = t / nb, C = t - R * nb;
-    double v = 0.0;
-    if (R == nb) {
-      v = yv[6 * (size_t)k0 + C];
-    } else if (C <= R) {
-      const int ii = R / 6, kk = C / 6;
-      if (ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)];
-    }
-    D[R * LDD + C] = v;
+  const int R = lane;                 // rows 0..nb-1: block rows; row nb: the right-hand side
+  const int ii = R / 6, rr = R - 6 * ii;
+  double row[NB];
+#pragma unroll
+  for (int c = 0; c < NB; ++c) row[c] = 0.0;
+  if (R < nb) {
+#pragma unroll
+    for (int kk = 0; kk < PB; ++kk)
+      if (kk <= ii && ii - kk <= band) {
+        const double* b = blk_ptr(Sb, band, k0 + ii, k0 + kk) + 6 * rr;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) row[6 * kk + c] = b[c];
+      }
+  } else if (R == nb) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c < nb) row[c] = yv[6 * (size_t)k0 + c];
   }
-  __syncthreads();
-  for (int c = 0; c < nb; ++c) {
-    if (tid == 0) {
-      double d = D[c * LDD + c];
+  int bad = 0;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    if (c < nb) {   // wave-uniform
+      double d = bcast_lane(row[c], c);
       if (!(d > 0.0)) {
-        if (status[0] == 0) status[0] = 6 * k0 + c + 1;
+        if (bad == 0) bad = 6 * k0 + c + 1;
         d = 1.0;
       }
-      D[c * LDD + c] = sqrt(d);
+      const double rs = rsqrt_newton(d);
+      const double l = (R == c) ? d * rs : row[c] * rs;
+      row[c] = l;
+      s_l[c & 1][lane] = l;
+      __syncthreads();
+#pragma unroll
+      for (int C = c + 1; C < NB; ++C) row[C] -= l * s_l[c & 1][C];   // columns C > R only touch the unused upper part
     }
-    __syncthreads();
-    const double inv = 1.0 / D[c * LDD + c];
-    for (int R = c + 1 + tid; R <= nb; R += 256) D[R * LDD + c] *= inv;
-    __syncthreads();
-    // trailing update of the panel block and the rhs row
-    const int m = nb - c;  // rows c+1..nb  (m of them), columns c+1..min(R, nb-1)
-    for (int t = tid; t < m * m; t += 256) {
-      const int R = c + 1 + t / m, C = c + 1 + t % m;
-      if (C <= R && C < nb) D[R * LDD + C] -= D[R * LDD + c] * D[C * LDD + c];
-    }
-    __syncthreads();
   }
-  for (int t = tid; t < (nb + 1) * nb; t += 256) {
-    const int R = t / nb, C = t - R * nb;
-    if (R == nb) {
-      yv[6 * (size_t)k0 + C] = D[R * LDD + C];
-    } else if (C <= R) {
-      const int ii = R / 6, kk = C / 6;
-      if (ii - kk <= band) blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)] = D[R * LDD + C];
-    } else if (R / 6 == C / 6) {
-      // keep the diagonal 6x6 blocks' upper parts harmless (zero): only the lower factor is used
-      blk_ptr(Sb, band, k0 + R / 6, k0 + C / 6)[6 * (R % 6) + (C % 6)] = 0.0;
-    }
+  if (bad != 0 && lane == 0 && status[0] == 0) status[0] = bad;
+  if (R < nb) {
+#pragma unroll
+    for (int kk = 0; kk < PB; ++kk)
+      if (kk <= ii && ii - kk <= band) {
+        double* b = blk_ptr(Sb, band, k0 + ii, k0 + kk) + 6 * rr;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) b[c] = (6 * kk + c <= R) ? row[6 * kk + c] : 0.0;   // strict upper part of the diagonal blocks = 0
+      }
+  } else if (R == nb) {
+#pragma unroll
+    for (int c = 0; c < NB; ++c)
+      if (c < nb) yv[6 * (size_t)k0 + c] = row[c];
   }
 }
 
-// Rows below the panel: L_row,panel = A_row,panel * L_D^-T, one scalar row per thread (row staged in LDS).
-constexpr int TRSM_T = 128;
+// Rows below the panel: L_row,panel = A_row,panel * L_D^-T, one scalar row per lane.  The row lives
+// in LDS transposed (Xs[column][lane]: conflict-free), L_D is read with broadcasts; the substitution
+// walks the 6x6 blocks so only 6 accumulators + 6 operands are live in registers.
+constexpr int TRSM_T = 64;
 __global__ __launch_bounds__(TRSM_T) void chol_trsm_kernel(double* __restrict__ Sb, int n_poses, int band, int k0) {
   __shared__ double L[NB * LDD];
-  __shared__ double X[TRSM_T * LDD];
+  __shared__ double invd[NB];
+  __shared__ double Xs[NB * TRSM_T];
   const int tid = threadIdx.x;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
-  for (int t = tid; t < nb * nb; t += TRSM_T) {
-    const int R = t / nb, C = t - R * nb;
+  for (int t = tid; t < NB * NB; t += TRSM_T) {
+    const int R = t / NB, C = t - R * NB;
     double v = 0.0;
     const int ii = R / 6, kk = C / 6;
-    if (C <= R && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)];
+    if (R < nb && C <= R && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)];
     L[R * LDD + C] = v;
+    if (R == C) invd[R] = (R < nb) ? 1.0 / v : 1.0;
   }
   const int i_first = k0 + pb;
   const int i_last = min(n_poses - 1, k0 + pb - 1 + band);
-  const int row = blockIdx.x * TRSM_T + tid;  // scalar row index inside the window
+  const int row = blockIdx.x * TRSM_T + tid;   // scalar row index inside the window
   const int i = i_first + row / 6, rr = row % 6;
   const bool active = i <= i_last;
-  int kk_min = 0;
-  double* x = X + tid * LDD;
-  if (active) {
-    kk_min = max(0, i - band - k0);  // first panel pose inside this row's band
-    for (int kk = kk_min; kk < pb; ++kk) {
-      const double* b = blk_ptr(Sb, band, i, k0 + kk) + 6 * rr;
+  const int kk_min = active ? max(0, i - band - k0) : PB;   // first panel pose inside this row's band
+  for (int kk = 0; kk < PB; ++kk) {
+    const bool have = kk >= kk_min && kk < pb;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) x[6 * kk + c] = b[c];
-    }
+    for (int c = 0; c < 6; ++c)
+      Xs[(6 * kk + c) * TRSM_T + tid] = have ? blk_ptr(Sb, band, i, k0 + kk)[6 * rr + c] : 0.0;
   }
   __syncthreads();
-  if (active) {
-    for (int c = 6 * kk_min; c < nb; ++c) {
-      double t = x[c];
-      for (int k = 6 * kk_min; k < c; ++k) t -= x[k] * L[c * LDD + k];
-      x[c] = t / L[c * LDD + c];
-    }
-    for (int kk = kk_min; kk < pb; ++kk) {
-      double* b = blk_ptr(Sb, band, i, k0 + kk) + 6 * rr;
+  // forward substitution; entries left of the band are zero and stay zero
+#pragma unroll 1
+  for (int kk = 0; kk < pb; ++kk) {
+    double t[6];
 #pragma unroll
-      for (int c = 0; c < 6; ++c) b[c] = x[6 * kk + c];
+    for (int c = 0; c < 6; ++c) t[c] = Xs[(6 * kk + c) * TRSM_T + tid];
+#pragma unroll 1
+    for (int k2 = 0; k2 < kk; ++k2) {
+      double xv[6];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) xv[k] = Xs[(6 * k2 + k) * TRSM_T + tid];
+      const double* Lb = L + (6 * kk) * LDD + 6 * k2;
+#pragma unroll
+      for (int c = 0; c < 6; ++c)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) t[c] -= xv[k] * Lb[c * LDD + k];
     }
+    const double* Ld = L + (6 * kk) * LDD + 6 * kk;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+#pragma unroll
+      for (int k = 0; k < c; ++k) t[c] -= t[k] * Ld[c * LDD + k];
+      t[c] *= invd[6 * kk + c];
+    }
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Xs[(6 * kk + c) * TRSM_T + tid] = t[c];
+  }
+  for (int kk = kk_min; kk < pb; ++kk) {
+    double* b = blk_ptr(Sb, band, i, k0 + kk) + 6 * rr;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) b[c] = Xs[(6 * kk + c) * TRSM_T + tid];
   }
 }
 
-// Trailing update of one pose row i of the window: A_ij -= L_i,panel L_j,panel^T for j in [max(first, i-band), i],
-// and the rhs rides along: y_i -= L_i,panel y_panel.
+// Trailing update of the window (SYRK): A_ij -= X_i X_j^T for window poses j <= i, where X = the
+// panel columns just produced by chol_trsm.  One workgroup per 96x96 tile (16x16 poses) of the lower
+// triangle, 36 MFMA tiles of 16x16 shared by 4 waves, K = 48 = 12 steps of v_mfma_f64_16x16x4_f64.
+// The right-hand side rides along: y_i -= X_i y_panel (done by the diagonal tiles).
+constexpr int UT = 96;            // scalar rows per tile
+constexpr int UTP = UT / 6;       // poses per tile
+constexpr int ULD = NB + 1;       // LDS row stride (doubles)
+typedef double double4_t __attribute__((ext_vector_type(4)));
+
 __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
                                                           double* __restrict__ yv) {
-  __shared__ double Li[6 * NB];
-  const int tid = threadIdx.x;
+  __shared__ double Xi[UT * ULD];
+  __shared__ double Xj[UT * ULD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
   const int i_first = k0 + pb;
-  const int i = i_first + blockIdx.x;
-  const int kk_min = max(0, i - band - k0);
-  for (int t = tid; t < 6 * nb; t += 256) {
-    const int rr = t / nb, c = t - rr * nb;
-    const int kk = c / 6;
-    Li[rr * NB + c] = kk >= kk_min ? blk_ptr(Sb, band, i, k0 + kk)[6 * rr + (c % 6)] : 0.0;
+  const int i_last = min(n_poses - 1, k0 + pb - 1 + band);
+  // tile (ti, tj), tj <= ti, from the linear block index
+  int ti = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
+  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
+  const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
+  const int pi0 = i_first + ti * UTP, pj0 = i_first + tj * UTP;   // first pose of the tile rows / columns
+  // stage X_i and X_j (rows x 48) in LDS; rows past the window or left of the band are zero
+  for (int t = tid; t < 2 * UT * PB; t += 256) {
+    const int which = t / (UT * PB);
+    const int u = t - which * (UT * PB);
+    const int lr = u / PB, kk = u - lr * PB;     // local scalar row, panel pose
+    const int i = (which ? pj0 : pi0) + lr / 6, rr = lr % 6;
+    double* dst = (which ? Xj : Xi) + lr * ULD + 6 * kk;
+    const bool have = i <= i_last && kk < pb && kk >= max(0, i - band - k0);
+    const double* b = have ? blk_ptr(Sb, band, i, k0 + kk) + 6 * rr : nullptr;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) dst[c] = have ? b[c] : 0.0;
   }
   __syncthreads();
-  const int j_first = max(i_first, i - band);
-  const int n_tasks = (i - j_first + 1) * 36;
-  for (int t = tid; t < n_tasks; t += 256) {
-    const int j = j_first + t / 36, e = t % 36;
-    const int rr = e / 6, c = e - 6 * rr;
-    double acc = 0.0;
-    for (int kk = kk_min; kk < pb; ++kk) {  // kk_min(i) >= kk_min(j): both factors exist
-      const double* lj = blk_ptr(Sb, band, j, k0 + kk) + 6 * c;
-      const double* li = Li + rr * NB + 6 * kk;
+  const int arow = lane & 15, kq = lane >> 4;
+  for (int t = wave; t < 36; t += 4) {
+    const int a = t / 6, b = t - 6 * a;          // MFMA tile (a, b) of the 6x6 grid
+    if (ti == tj && b > a) continue;             // strictly upper tiles of a diagonal workgroup
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    const double* pa = Xi + (16 * a + arow) * ULD + kq;
+    const double* pbm = Xj + (16 * b + arow) * ULD + kq;
 #pragma unroll
-      for (int u = 0; u < 6; ++u) acc += li[u] * lj[u];
+    for (int s = 0; s < NB / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pbm[4 * s], acc, 0, 0, 0);
+    // C/D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+    const int Cc = 16 * b + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int Rr = 16 * a + (lane >> 4) + 4 * r;
+      const int i = pi0 + Rr / 6, j = pj0 + Cc / 6;
+      if (i <= i_last && j <= i && (j < i || (Cc % 6) <= (Rr % 6)))
+        blk_ptr(Sb, band, i, j)[6 * (Rr % 6) + (Cc % 6)] -= acc[r];
     }
-    blk_ptr(Sb, band, i, j)[e] -= acc;
   }
-  if (tid < 6) {
-    double acc = 0.0;
-    for (int c = 6 * kk_min; c < nb; ++c) acc += Li[tid * NB + c] * yv[6 * (size_t)k0 + c];
-    yv[6 * (size_t)i + tid] -= acc;
+  if (ti == tj && tid < UT) {
+    const int i = pi0 + tid / 6;
+    if (i <= i_last) {
+      double acc = 0.0;
+      for (int c = 0; c < nb; ++c) acc += Xi[tid * ULD + c] * yv[6 * (size_t)k0 + c];
+      yv[6 * (size_t)i + (tid % 6)] -= acc;
+    }
   }
 }
 
-// x = L^-T y in place (yv), right-looking from the last pose to the first, one workgroup.
-// The working vector lives in LDS when it fits (n <= 12288 scalars), else in global memory.
+// x = L^-T y in place (yv), from the last panel to the first, one workgroup.  Per panel: the 48x48
+// triangular solve runs on wave 0 (lane = row, right-looking, x broadcast with readlane), then all
+// threads subtract the panel's contribution from the rows above it.  y lives in LDS when it fits.
 constexpr int BS_THREADS = 1024;
 constexpr int BS_LDS_N = 12288;
 __global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(const double* __restrict__ Sb, int n_poses,
                                                                     int band, double* __restrict__ yv) {
   extern __shared__ double s_y[];
+  __shared__ double s_L[NB * LDD];
+  __shared__ double s_x[NB];
   const int tid = threadIdx.x;
   const int n = 6 * n_poses;
   const bool in_lds = n <= BS_LDS_N;
   double* y = in_lds ? s_y : yv;
-  if (in_lds) {
+  if (in_lds)
     for (int t = tid; t < n; t += BS_THREADS) s_y[t] = yv[t];
-  }
-  __syncthreads();
-  for (int k = n_poses - 1; k >= 0; --k) {
-    const double* Lkk = Sb + 36 * (size_t)k * (band + 1);
-    if (tid == 0) {
-      double x[6];
-#pragma unroll
-      for (int c = 5; c >= 0; --c) {
-        double t = y[6 * k + c];
-#pragma unroll
-        for (int r = c + 1; r < 6; ++r) t -= Lkk[6 * r + c] * x[r];
-        x[c] = t / Lkk[7 * c];
-      }
-#pragma unroll
-      for (int c = 0; c < 6; ++c) y[6 * k + c] = x[c];
+  const int n_panels = (n_poses + PB - 1) / PB;
+  for (int p = n_panels - 1; p >= 0; --p) {
+    const int k0 = p * PB;
+    const int pb = min(PB, n_poses - k0), nb = 6 * pb;
+    for (int t = tid; t < NB * NB; t += BS_THREADS) {   // the panel's lower-triangular diagonal block
+      const int R = t / NB, C = t - R * NB;
+      const int ii = R / 6, kk = C / 6;
+      double v = (R == C) ? 1.0 : 0.0;
+      if (R < nb && C <= R && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)];
+      s_L[R * LDD + C] = v;
     }
     __syncthreads();
-    const int nrows = min(band, k);
-    for (int t = tid; t < 6 * nrows; t += BS_THREADS) {
-      const int i = k - 1 - t / 6, c = t % 6;
-      const double* Lki = Sb + 36 * ((size_t)k * (band + 1) + (k - i));
+    if (tid < 64) {
+      double yr = tid < nb ? y[6 * k0 + tid] : 0.0;
+      for (int c = nb - 1; c >= 0; --c) {     // L^T x = y: x_c = y_c / L_cc, then y_r -= L_cr x_c for r < c
+        const double xc = bcast_lane(yr, c) / s_L[c * LDD + c];
+        if (tid == c) yr = xc;
+        else if (tid < c) yr -= s_L[c * LDD + tid] * xc;
+      }
+      if (tid < nb) { y[6 * k0 + tid] = yr; s_x[tid] = yr; }
+    }
+    __syncthreads();
+    const int i0 = max(0, k0 - band);   // rows above the panel that hold a block in some panel row
+    for (int t = tid; t < 6 * (k0 - i0); t += BS_THREADS) {
+      const int i = i0 + t / 6, c = t % 6;
       double acc = 0.0;
+      for (int kk = 0; kk < pb; ++kk) {
+        if (k0 + kk - i > band) break;
+        const double* Lki = blk_ptr(Sb, band, k0 + kk, i) + c;
 #pragma unroll
-      for (int r = 0; r < 6; ++r) acc += Lki[6 * r + c] * y[6 * k + r];
+        for (int r = 0; r < 6; ++r) acc += Lki[6 * r] * s_x[6 * kk + r];
+      }
       y[6 * i + c] -= acc;
     }
     __syncthreads();
   }
-  if (in_lds) {
+  if (in_lds)
     for (int t = tid; t < n; t += BS_THREADS) yv[t] = s_y[t];
-  }
 }
 
 __global__ void add_diag_kernel(double* __restrict__ Sband, int n_poses, int band, double value) {
@@ -834,7 +922,7 @@ extern "C" int vus_ba_band_solve(double* Sband, int n_poses, int band, const dou
   VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
   negate_copy_kernel<<<cdiv(n, 256), 256, 0, st>>>(gs, dp, n);
   for (int k0 = 0; k0 < n_poses; k0 += PB) {
-    chol_panel_kernel<<<1, 256, 0, st>>>(Sband, n_poses, band, k0, dp, status);
+    chol_panel_kernel<<<1, 64, 0, st>>>(Sband, n_poses, band, k0, dp, status);
     const int pb = n_poses - k0 < PB ? n_poses - k0 : PB;
     const int i_first = k0 + pb;
     int i_last = k0 + pb - 1 + band;
@@ -842,7 +930,8 @@ extern "C" int vus_ba_band_solve(double* Sband, int n_poses, int band, const dou
     const int rows = i_last - i_first + 1;
     if (rows > 0) {
       chol_trsm_kernel<<<cdiv(6ll * rows, TRSM_T), TRSM_T, 0, st>>>(Sband, n_poses, band, k0);
-      chol_update_kernel<<<rows, 256, 0, st>>>(Sband, n_poses, band, k0, dp);
+      const int tiles = (rows + UTP - 1) / UTP;
+      chol_update_kernel<<<tiles * (tiles + 1) / 2, 256, 0, st>>>(Sband, n_poses, band, k0, dp);
     }
   }
   const size_t lds = n <= BS_LDS_N ? sizeof(double) * (size_t)n : 0;

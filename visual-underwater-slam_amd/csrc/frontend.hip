@@ -27,8 +27,14 @@
 
 namespace {
 
-constexpr int TW = 128;                 // output tile width  (1280 = 10 tiles)
-constexpr int TH = 48;                  // output tile height (720 = 15 tiles)
+#ifndef VUS_TW
+#define VUS_TW 128
+#endif
+#ifndef VUS_TH
+#define VUS_TH 48
+#endif
+constexpr int TW = VUS_TW;              // output tile width  (1280 = 10 tiles of 128)
+constexpr int TH = VUS_TH;              // output tile height (720 = 15 tiles of 48)
 constexpr int NTHREADS = 256;
 // LDS images are arrays of dwords = 4 horizontally adjacent pixels ("strips"); every phase reads
 // ds_read_b32/b64 and unpacks bytes in registers (byte-wide LDS reads cost ~3x the LDS cycles).
@@ -333,7 +339,10 @@ constexpr int OR_DW = 9;                    // 36 bytes cover x-15..x+15 from an
 constexpr int BR_R = VUS_RBRIEF_REACH;      // 18
 constexpr int BR_ROWS = 2 * BR_R + 1;       // 37
 constexpr int BR_DW = 10;                   // 40 bytes cover x-18..x+18 from an aligned start
-constexpr int OR_KP_PER_WAVE = 4;           // keypoints handled sequentially by one wave
+#ifndef VUS_OR_KPW
+#define VUS_OR_KPW 10
+#endif
+constexpr int OR_KP_PER_WAVE = VUS_OR_KPW;  // keypoints handled sequentially by one wave
 constexpr int OR_DISC_ITERS = (VUS_DISC_N + 63) / 64;
 
 __device__ __forceinline__ void stage_patch(const uint8_t* __restrict__ src, int H, int W, int pitch, int y, int x,
