@@ -540,13 +540,26 @@ __global__ __launch_bounds__(TRSM_T) void chol_trsm_kernel(double* __restrict__ 
   const int tid = threadIdx.x;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
-  for (int t = tid; t < NB * NB; t += TRSM_T) {
-    const int R = t / NB, C = t - R * NB;
-    double v = 0.0;
-    const int ii = R / 6, kk = C / 6;
-    if (R < nb && C <= R && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)];
-    L[R * LDD + C] = v;
-    if (R == C) invd[R] = (R < nb) ? 1.0 / v : 1.0;
+  {
+    // all loads of the 48x48 block are issued before the first LDS store (36 independent loads per lane)
+    double v[NB * NB / TRSM_T];
+#pragma unroll
+    for (int u = 0; u < NB * NB / TRSM_T; ++u) {
+      const int t = tid + TRSM_T * u;
+      const int R = t / NB, C = t - R * NB;
+      const int ii = R / 6, kk = C / 6;
+      const bool have = R < nb && C <= R && ii - kk <= band;
+      const double* src = blk_ptr(Sb, band, k0 + (have ? ii : 0), k0) + (have ? -36 * kk + 6 * (R % 6) + (C % 6) : 0);
+      v[u] = *src;   // block (k0,k0) element 0 is always a valid address
+      if (!have) v[u] = 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < NB * NB / TRSM_T; ++u) {
+      const int t = tid + TRSM_T * u;
+      const int R = t / NB, C = t - R * NB;
+      L[R * LDD + C] = v[u];
+      if (R == C) invd[R] = (R < nb) ? 1.0 / v[u] : 1.0;
+    }
   }
   const int i_first = k0 + pb;
   const int i_last = min(n_poses - 1, k0 + pb - 1 + band);
@@ -554,11 +567,20 @@ __global__ __launch_bounds__(TRSM_T) void chol_trsm_kernel(double* __restrict__ 
   const int i = i_first + row / 6, rr = row % 6;
   const bool active = i <= i_last;
   const int kk_min = active ? max(0, i - band - k0) : PB;   // first panel pose inside this row's band
-  for (int kk = 0; kk < PB; ++kk) {
-    const bool have = kk >= kk_min && kk < pb;
+  {
+    double a[NB];
 #pragma unroll
-    for (int c = 0; c < 6; ++c)
-      Xs[(6 * kk + c) * TRSM_T + tid] = have ? blk_ptr(Sb, band, i, k0 + kk)[6 * rr + c] : 0.0;
+    for (int kk = 0; kk < PB; ++kk) {
+      const bool have = kk >= kk_min && kk < pb;
+      const double* src = have ? blk_ptr(Sb, band, i, k0 + kk) + 6 * rr : blk_ptr(Sb, band, k0, k0);
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        a[6 * kk + c] = src[have ? c : 0];
+        if (!have) a[6 * kk + c] = 0.0;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NB; ++c) Xs[c * TRSM_T + tid] = a[c];
   }
   __syncthreads();
   // forward substitution; entries left of the band are zero and stay zero
@@ -633,22 +655,46 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ S
   }
   __syncthreads();
   const int arow = lane & 15, kq = lane >> 4;
-  for (int t = wave; t < 36; t += 4) {
-    const int a = t / 6, b = t - 6 * a;          // MFMA tile (a, b) of the 6x6 grid
-    if (ti == tj && b > a) continue;             // strictly upper tiles of a diagonal workgroup
-    double4_t acc = {0.0, 0.0, 0.0, 0.0};
-    const double* pa = Xi + (16 * a + arow) * ULD + kq;
-    const double* pbm = Xj + (16 * b + arow) * ULD + kq;
+  // this wave's 9 MFMA tiles: accumulate X_i X_j^T - A and store the negation, so the old values
+  // enter as the C operand (their loads overlap the LDS reads) instead of a read-modify-write tail
+  double4_t acc[9];
+  bool ok[9][4];
 #pragma unroll
-    for (int s = 0; s < NB / 4; ++s) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pbm[4 * s], acc, 0, 0, 0);
-    // C/D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+  for (int q = 0; q < 9; ++q) {
+    const int t = wave + 4 * q;
+    const int a = t / 6, b = t - 6 * a;
     const int Cc = 16 * b + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int Rr = 16 * a + (lane >> 4) + 4 * r;
       const int i = pi0 + Rr / 6, j = pj0 + Cc / 6;
-      if (i <= i_last && j <= i && (j < i || (Cc % 6) <= (Rr % 6)))
-        blk_ptr(Sb, band, i, j)[6 * (Rr % 6) + (Cc % 6)] -= acc[r];
+      ok[q][r] = i <= i_last && j <= i && (j < i || (Cc % 6) <= (Rr % 6));
+      const double* src = ok[q][r] ? blk_ptr(Sb, band, i, j) + 6 * (Rr % 6) + (Cc % 6) : Sb;
+      acc[q][r] = -*src;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int t = wave + 4 * q;
+    const int a = t / 6, b = t - 6 * a;
+    if (ti == tj && b > a) continue;             // strictly upper tiles of a diagonal workgroup
+    const double* pa = Xi + (16 * a + arow) * ULD + kq;
+    const double* pbm = Xj + (16 * b + arow) * ULD + kq;
+#pragma unroll
+    for (int s = 0; s < NB / 4; ++s) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pbm[4 * s], acc[q], 0, 0, 0);
+  }
+  // C/D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int q = 0; q < 9; ++q) {
+    const int t = wave + 4 * q;
+    const int a = t / 6, b = t - 6 * a;
+    if (ti == tj && b > a) continue;
+    const int Cc = 16 * b + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int Rr = 16 * a + (lane >> 4) + 4 * r;
+      const int i = pi0 + Rr / 6, j = pj0 + Cc / 6;
+      if (ok[q][r]) blk_ptr(Sb, band, i, j)[6 * (Rr % 6) + (Cc % 6)] = -acc[q][r];
     }
   }
   if (ti == tj && tid < UT) {
@@ -686,13 +732,13 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(const double
       const int ii = R / 6, kk = C / 6;
       double v = (R == C) ? 1.0 : 0.0;
       if (R < nb && C <= R && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)];
-      s_L[R * LDD + C] = v;
+      s_L[R * LDD + C] = (R == C) ? 1.0 / v : v;   // the diagonal is stored inverted
     }
     __syncthreads();
     if (tid < 64) {
       double yr = tid < nb ? y[6 * k0 + tid] : 0.0;
       for (int c = nb - 1; c >= 0; --c) {     // L^T x = y: x_c = y_c / L_cc, then y_r -= L_cr x_c for r < c
-        const double xc = bcast_lane(yr, c) / s_L[c * LDD + c];
+        const double xc = bcast_lane(yr, c) * s_L[c * LDD + c];
         if (tid == c) yr = xc;
         else if (tid < c) yr -= s_L[c * LDD + tid] * xc;
       }
