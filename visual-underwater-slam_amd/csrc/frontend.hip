@@ -340,95 +340,184 @@ constexpr int BR_R = VUS_RBRIEF_REACH;      // 18
 constexpr int BR_ROWS = 2 * BR_R + 1;       // 37
 constexpr int BR_DW = 10;                   // 40 bytes cover x-18..x+18 from an aligned start
 #ifndef VUS_OR_KPW
-#define VUS_OR_KPW 10
+#define VUS_OR_KPW 8
 #endif
 constexpr int OR_KP_PER_WAVE = VUS_OR_KPW;  // keypoints handled sequentially by one wave
-constexpr int OR_DISC_ITERS = (VUS_DISC_N + 63) / 64;
 
-__device__ __forceinline__ void stage_patch(const uint8_t* __restrict__ src, int H, int W, int pitch, int y, int x,
-                                            int radius, int rows, int dw, uint32_t* __restrict__ dst, int lane,
-                                            bool aligned) {
-  const int xa = (x - radius) & ~3;   // aligned start column (floor)
-  const bool inside = aligned && y - radius >= 0 && y + radius < H && xa >= 0 && xa + 4 * dw <= W;
-  if (inside) {   // wave-uniform
-    for (int t = lane; t < rows * dw; t += 64) {
-      const int r = t / dw, c = t - r * dw;
-      dst[t] = *reinterpret_cast<const uint32_t*>(src + (size_t)(y - radius + r) * pitch + xa + 4 * c);
-    }
-  } else {        // replicate-clamped, byte by byte (keypoints near the image edge)
-    for (int t = lane; t < rows * dw; t += 64) {
-      const int r = t / dw, c = t - r * dw;
-      const uint8_t* rp = src + (size_t)clampi(y - radius + r, 0, H - 1) * pitch;
-      const int gx = xa + 4 * c;
-      dst[t] = (uint32_t)rp[clampi(gx, 0, W - 1)] | ((uint32_t)rp[clampi(gx + 1, 0, W - 1)] << 8) |
-               ((uint32_t)rp[clampi(gx + 2, 0, W - 1)] << 16) | ((uint32_t)rp[clampi(gx + 3, 0, W - 1)] << 24);
+// Load a (2*RADIUS+1) x (4*DW)-byte patch around (x, y) into registers: every lane issues all of
+// its dword loads back to back (one memory round trip), the caller stores them to LDS afterwards.
+template <int RADIUS, int DW>
+struct PatchRegs {
+  static constexpr int ROWS = 2 * RADIUS + 1;
+  static constexpr int N = ROWS * DW;
+  static constexpr int ITERS = (N + 63) / 64;
+  uint32_t v[ITERS];
+  int off[ITERS];   // byte offset of this lane's dwords inside an in-image patch (fixed per kernel)
+
+  __device__ __forceinline__ void init(int pitch, int lane) {
+#pragma unroll
+    for (int u = 0; u < ITERS; ++u) {
+      const int t = min(lane + 64 * u, N - 1);
+      off[u] = (t / DW) * pitch + 4 * (t % DW);
     }
   }
+  __device__ __forceinline__ void load(const uint8_t* __restrict__ src, int H, int W, int pitch, int y, int x,
+                                       int lane, bool aligned) {
+    const int xa = (x - RADIUS) & ~3;   // aligned start column (floor)
+    const bool inside = aligned && y - RADIUS >= 0 && y + RADIUS < H && xa >= 0 && xa + 4 * DW <= W;
+    if (inside) {   // wave-uniform
+      const uint8_t* base = src + (size_t)(y - RADIUS) * pitch + xa;
+#pragma unroll
+      for (int u = 0; u < ITERS; ++u) v[u] = *reinterpret_cast<const uint32_t*>(base + off[u]);
+    } else {        // replicate-clamped, byte by byte (keypoints near the image edge)
+#pragma unroll
+      for (int u = 0; u < ITERS; ++u) {
+        const int t = min(lane + 64 * u, N - 1);
+        const int r = t / DW, c = t - r * DW;
+        const uint8_t* rp = src + (size_t)clampi(y - RADIUS + r, 0, H - 1) * pitch;
+        const int gx = xa + 4 * c;
+        v[u] = (uint32_t)rp[clampi(gx, 0, W - 1)] | ((uint32_t)rp[clampi(gx + 1, 0, W - 1)] << 8) |
+               ((uint32_t)rp[clampi(gx + 2, 0, W - 1)] << 16) | ((uint32_t)rp[clampi(gx + 3, 0, W - 1)] << 24);
+      }
+    }
+  }
+  __device__ __forceinline__ void store(uint32_t* __restrict__ dst, int lane) const {
+#pragma unroll
+    for (int u = 0; u < ITERS; ++u)
+      if (lane + 64 * u < N) dst[lane + 64 * u] = v[u];
+  }
+};
+
+// Wave-wide integer sum with DPP row shifts / broadcasts (VALU latency instead of six LDS-crossbar
+// round trips); the total is read from lane 63 and returned wave-uniform.
+__device__ __forceinline__ int wave_sum_i32(int v) {
+  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, true);   // row_shr:4, banks 1-3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, true);   // row_shr:8, banks 2-3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+  return __builtin_amdgcn_readlane(v, 63);
 }
+
+__device__ const uint8_t kDiscUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 __global__ __launch_bounds__(256) void orient_rbrief_kernel(
     const uint8_t* __restrict__ img, const uint8_t* __restrict__ blur, int H, int W, int pitch,
     const uint32_t* __restrict__ kp_keys, const int* __restrict__ kp_count, int max_kp,
-    uint64_t* __restrict__ desc_out, uint8_t* __restrict__ angle_out) {
+    uint64_t* __restrict__ desc_out, uint8_t* __restrict__ angle_out, int n_img, int chunks_per_img) {
   __shared__ uint32_t s_raw[4][OR_ROWS * OR_DW];
   __shared__ uint32_t s_blur[4][BR_ROWS * BR_DW];
+  // centroid weights per patch dword, for the 4 possible byte alignments of the patch:
+  // s_wx = (dx + 15) inside the disc else 0 (u8 x 4), s_wm = 1 inside the disc else 0
+  __shared__ uint32_t s_wx[4 * OR_ROWS * OR_DW];
+  __shared__ uint32_t s_wm[4 * OR_ROWS * OR_DW];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int n = blockIdx.y;
+  // XCD-aware block -> (image, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so all
+  // chunks of one image go to blocks with equal (blockIdx % 8): the image's two 0.9 MB planes then
+  // stay in ONE XCD's 4 MiB L2 while its 2000 patches are gathered (placement affects speed only).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n = (slot / chunks_per_img) * 8 + xcd;
+  const int chunk = slot - (slot / chunks_per_img) * chunks_per_img;
+  if (n >= n_img) return;
+  for (int e = threadIdx.x; e < 4 * OR_ROWS * OR_DW; e += 256) {
+    const int sh = e / (OR_ROWS * OR_DW), t = e - sh * (OR_ROWS * OR_DW);
+    const int r = t / OR_DW, c = t - r * OR_DW;
+    const int dy = r - OR_R, um = kDiscUmax[dy < 0 ? -dy : dy];
+    uint32_t wx = 0, wm = 0;
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int dx = 4 * c + b - sh - OR_R;
+      if (dx >= -um && dx <= um) {
+        wx |= (uint32_t)(dx + OR_R) << (8 * b);
+        wm |= 1u << (8 * b);
+      }
+    }
+    s_wx[e] = wx;
+    s_wm[e] = wm;
+  }
   const uint8_t* im = img + (size_t)n * H * pitch;
   const uint8_t* bl = blur + (size_t)n * H * W;
   const bool al_img = ((reinterpret_cast<uintptr_t>(im) | (uintptr_t)pitch) & 3u) == 0;
   const bool al_blur = ((reinterpret_cast<uintptr_t>(bl) | (uintptr_t)W) & 3u) == 0;
   const int count = kp_count[n];
-  const uint8_t* raw8 = reinterpret_cast<const uint8_t*>(s_raw[wave]);
   const uint8_t* blur8 = reinterpret_cast<const uint8_t*>(s_blur[wave]);
-  // this lane's share of the disc: byte offset inside the staged patch and the moment weights
-  int disc_off[OR_DISC_ITERS], disc_dx[OR_DISC_ITERS], disc_dy[OR_DISC_ITERS];
+  // this lane's share of the centroid patch: row offsets dy of its dwords
+  constexpr int MOM_ITERS = (OR_ROWS * OR_DW + 63) / 64;
+  int mom_dy[MOM_ITERS];
 #pragma unroll
-  for (int k = 0; k < OR_DISC_ITERS; ++k) {
-    const int e = lane + 64 * k;
-    const bool v = e < VUS_DISC_N;
-    disc_dx[k] = v ? VUS_DISC_DX[e] : 0;
-    disc_dy[k] = v ? VUS_DISC_DY[e] : 0;
-    disc_off[k] = v ? (disc_dy[k] + OR_R) * (4 * OR_DW) + disc_dx[k] + OR_R : 0;
-  }
-  for (int it = 0; it < OR_KP_PER_WAVE; ++it) {   // uniform trip count: barriers are legal
-    const int i = (blockIdx.x * OR_KP_PER_WAVE + it) * 4 + wave;
-    const bool live = i < count && i < max_kp;
-    int y = 0, x = 0;
+  for (int u = 0; u < MOM_ITERS; ++u) mom_dy[u] = min(lane + 64 * u, OR_ROWS * OR_DW - 1) / OR_DW - OR_R;
+  // software pipeline over this wave's keypoints: the patch loads of keypoint it+1 are in flight
+  // while keypoint it is reduced out of LDS
+  auto kp_xy = [&](int it, int& i, bool& live, int& y, int& x) {
+    i = (chunk * OR_KP_PER_WAVE + it) * 4 + wave;
+    live = i < count && i < max_kp;
+    y = 0; x = 0;
     if (live) {
       const uint32_t pos = kp_keys[(size_t)n * max_kp + i] & VUS_KEY_POS_MASK;
       y = (int)(pos / (uint32_t)W);
       x = (int)(pos - (uint32_t)y * (uint32_t)W);
-      stage_patch(im, H, W, pitch, y, x, OR_R, OR_ROWS, OR_DW, s_raw[wave], lane, al_img);
-      stage_patch(bl, H, W, W, y, x, BR_R, BR_ROWS, BR_DW, s_blur[wave], lane, al_blur);
     }
-    __syncthreads();
+  };
+  PatchRegs<OR_R, OR_DW> pr;
+  PatchRegs<BR_R, BR_DW> pb;
+  pr.init(pitch, lane);
+  pb.init(W, lane);
+  int i, y, x;
+  bool live;
+  kp_xy(0, i, live, y, x);
+  if (live) {
+    pr.load(im, H, W, pitch, y, x, lane, al_img);
+    pb.load(bl, H, W, W, y, x, lane, al_blur);
+  }
+  for (int it = 0; it < OR_KP_PER_WAVE; ++it) {   // uniform trip count: barriers are legal
     if (live) {
-      const int sh_raw = (x - OR_R) & 3, sh_blur = (x - BR_R) & 3;   // patch column of x-radius
-      int m10 = 0, m01 = 0;
-#pragma unroll
-      for (int k = 0; k < OR_DISC_ITERS; ++k) {
-        const int v = (lane + 64 * k < VUS_DISC_N) ? raw8[disc_off[k] + sh_raw] : 0;
-        m10 += disc_dx[k] * v;
-        m01 += disc_dy[k] * v;
+      pr.store(s_raw[wave], lane);
+      pb.store(s_blur[wave], lane);
+    }
+    __syncthreads();   // also orders the weight tables before their first use
+    const int ci = i, cx = x;
+    const bool clive = live;
+    if (it + 1 < OR_KP_PER_WAVE) {
+      kp_xy(it + 1, i, live, y, x);
+      if (live) {
+        pr.load(im, H, W, pitch, y, x, lane, al_img);
+        pb.load(bl, H, W, W, y, x, lane, al_blur);
       }
+    }
+    if (clive) {
+      const int sh_raw = (cx - OR_R) & 3, sh_blur = (cx - BR_R) & 3;   // patch column of x-radius
+      // centroid moments, 4 pixels per v_dot4_u32_u8:  sum (dx+15) I,  sum I,  sum dy I
+      int sx = 0, si = 0, sy = 0;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        m10 += __shfl_xor(m10, o);
-        m01 += __shfl_xor(m01, o);
+      for (int u = 0; u < MOM_ITERS; ++u) {
+        const int t = lane + 64 * u;
+        if (t < OR_ROWS * OR_DW) {
+          const uint32_t v = s_raw[wave][t];
+          const int e = sh_raw * (OR_ROWS * OR_DW) + t;
+          sx = (int)__builtin_amdgcn_udot4(v, s_wx[e], (uint32_t)sx, false);
+          const int rs = (int)__builtin_amdgcn_udot4(v, s_wm[e], 0u, false);
+          si += rs;
+          sy += mom_dy[u] * rs;
+        }
       }
+      sx = wave_sum_i32(sx);
+      si = wave_sum_i32(si);
+      const int m01 = wave_sum_i32(sy);
+      const int m10 = sx - OR_R * si;
       // nearest bin direction = largest projection, first maximum wins (integer, exact)
-      long long pr = lane < VUS_N_ANGLE_BINS
-                         ? (long long)m10 * VUS_ANGLE_COS[lane] + (long long)m01 * VUS_ANGLE_SIN[lane]
-                         : (long long)(-0x7FFFFFFFFFFFFFFFll - 1);
+      long long prj = lane < VUS_N_ANGLE_BINS
+                          ? (long long)m10 * VUS_ANGLE_COS[lane] + (long long)m01 * VUS_ANGLE_SIN[lane]
+                          : (long long)(-0x7FFFFFFFFFFFFFFFll - 1);
       int bin = lane;
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        long long opr = __shfl_xor(pr, o);
+      for (int o = 16; o > 0; o >>= 1) {   // the 30 bins live in lanes 0..29: 32 lanes suffice
+        long long opr = __shfl_xor(prj, o);
         int obin = __shfl_xor(bin, o);
-        if (opr > pr || (opr == pr && obin < bin)) { pr = opr; bin = obin; }
+        if (opr > prj || (opr == prj && obin < bin)) { prj = opr; bin = obin; }
       }
+      bin = __builtin_amdgcn_readfirstlane(bin);
       const char4* pat = reinterpret_cast<const char4*>(VUS_RBRIEF_ROT) + (size_t)bin * 256;
       const uint8_t* c = blur8 + BR_R * (4 * BR_DW) + BR_R + sh_blur;   // the keypoint inside the patch
       uint64_t word[4];
@@ -440,14 +529,14 @@ __global__ __launch_bounds__(256) void orient_rbrief_kernel(
         word[w] = __ballot(a < b);  // lane l supplies bit l of word w
       }
       if (lane == 0) {
-        uint64_t* d = desc_out + ((size_t)n * max_kp + i) * 4;
+        uint64_t* d = desc_out + ((size_t)n * max_kp + ci) * 4;
         d[0] = word[0]; d[1] = word[1]; d[2] = word[2]; d[3] = word[3];
-        angle_out[(size_t)n * max_kp + i] = (uint8_t)bin;
+        angle_out[(size_t)n * max_kp + ci] = (uint8_t)bin;
       }
-    } else if (i < max_kp) {   // unused slot: defined contents
-      uint64_t* d = desc_out + ((size_t)n * max_kp + i) * 4;
+    } else if (ci < max_kp) {   // unused slot: defined contents
+      uint64_t* d = desc_out + ((size_t)n * max_kp + ci) * 4;
       if (lane < 4) d[lane] = 0;
-      if (lane == 0) angle_out[(size_t)n * max_kp + i] = 0;
+      if (lane == 0) angle_out[(size_t)n * max_kp + ci] = 0;
     }
     __syncthreads();
   }
@@ -698,9 +787,11 @@ extern "C" int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_
   VUS_REQUIRE(blur && kp_keys && kp_count && desc_out && angle_out, "null buffer");
   VUS_REQUIRE(max_kp >= 1, "max_kp=%d", max_kp);
   if (n_img == 0) return VUS_OK;
-  dim3 grid((max_kp + 4 * OR_KP_PER_WAVE - 1) / (4 * OR_KP_PER_WAVE), n_img);
-  orient_rbrief_kernel<<<grid, 256, 0, vus::as_stream(stream)>>>(img, blur, H, W, pitch, kp_keys, kp_count,
-                                                              max_kp, desc_out, angle_out);
+  const int chunks = (max_kp + 4 * OR_KP_PER_WAVE - 1) / (4 * OR_KP_PER_WAVE);
+  const long long blocks = (long long)((n_img + 7) / 8) * 8 * chunks;
+  VUS_REQUIRE(blocks < (1ll << 31), "too many workgroups (%lld)", blocks);
+  orient_rbrief_kernel<<<(unsigned)blocks, 256, 0, vus::as_stream(stream)>>>(
+      img, blur, H, W, pitch, kp_keys, kp_count, max_kp, desc_out, angle_out, n_img, chunks);
   VUS_CHECK_LAUNCH("orient_rbrief");
   return VUS_OK;
 }
