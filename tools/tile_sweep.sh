@@ -1,7 +1,7 @@
 #!/bin/bash
 # Build libvus_hip.so with several FAST tile shapes and bench each (run on the GPU box).
 cd $GRAFT_REPO_ROOT/visual-underwater-slam_amd/csrc
-for cfg in "128 48" "64 48" "128 24" "64 24" "256 24" "32 48"; do
+for cfg in "128 24" "128 16" "128 12" "128 36" "64 36" "256 12" "256 16"; do
   set -- $cfg
   /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -DVUS_TW=$1 -DVUS_TH=$2 -c frontend.hip -o frontend.o 2>/dev/null
   /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 vus_common.o frontend.o ba.o -o libvus_hip.so

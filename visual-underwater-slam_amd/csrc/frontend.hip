@@ -10,13 +10,16 @@
 // Design notes (MI355X):
 //  * everything is batched over images: grid.z / grid.y = image, so one launch covers the whole
 //    resident stream and fills the 256 CUs;
-//  * fast_detect stages a 144x56 byte tile (128x48 outputs + halo) in LDS once, as dwords, and
+//  * fast_detect stages a 144x32 byte tile (128x24 outputs + halo) in LDS once, as dwords, and
 //    derives score, non-max suppression and the 7x7 smoothing from it: the image is read from HBM
 //    once; the score map never goes to HBM (candidates leave the CU as 4-byte keys);
 //  * every thread works on strips of 4 adjacent pixels read with ds_read_b32/b64 and unpacked in
 //    registers (SDWA byte selects): byte-wide LDS reads made the first version LDS-issue bound;
-//  * the score is computed branch-free for every pixel with v_min3/v_max3 sliding windows
-//    (no divergence on corner density); the smoothing uses v_dot4_u32_u8 on v_alignbyte windows;
+//  * scoring is two-pass: a 10-op necessary test (compass points N/S/E/W) on every pixel, survivors
+//    compacted into an LDS work list (DPP wave scan), then the exact score with v_min3/v_max3
+//    sliding windows on dense lanes; the smoothing uses v_dot4_u32_u8 on v_alignbyte windows.
+//    The integer min/max/SDWA ops issue at ~0.57x the fp32 rate on gfx950 (tools/ubench): the
+//    kernel is VALU-issue bound, so the lever is instruction count, not bytes;
 //  * select_topk is an exact 4x8-bit MSB radix select + LDS bitonic sort, one workgroup per image;
 //  * orient_rbrief uses one 64-lane wave per keypoint: lane-strided disc moments, integer bin
 //    choice, and the descriptor words come straight out of __ballot (lane = test bit);
@@ -31,10 +34,10 @@ namespace {
 #define VUS_TW 128
 #endif
 #ifndef VUS_TH
-#define VUS_TH 48
+#define VUS_TH 24
 #endif
 constexpr int TW = VUS_TW;              // output tile width  (1280 = 10 tiles of 128)
-constexpr int TH = VUS_TH;              // output tile height (720 = 15 tiles of 48)
+constexpr int TH = VUS_TH;              // output tile height (720 = 30 tiles of 24)
 constexpr int NTHREADS = 256;
 // LDS images are arrays of dwords = 4 horizontally adjacent pixels ("strips"); every phase reads
 // ds_read_b32/b64 and unpacks bytes in registers (byte-wide LDS reads cost ~3x the LDS cycles).
@@ -105,7 +108,8 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
   __shared__ uint32_t s_img[IMG_ROWS * IMG_DW];
   __shared__ uint32_t s_score[(WRITE_SCORE || DETECT) ? SC_ROWS * SC_DW : 1];
   __shared__ uint32_t s_h[BLUR ? H_ROWS * H_DW : 2];
-  __shared__ int s_cnt, s_base;
+  __shared__ uint16_t s_work[(WRITE_SCORE || DETECT) ? SC_ROWS * SC_DW * 4 : 2];   // pixels that pass the pre-test
+  __shared__ int s_cnt, s_base, s_nwork;
   // the candidate list reuses the image tile, which is dead after the second barrier
   static_assert(IMG_ROWS * IMG_DW >= TW * TH / 4, "candidate list must fit in the image tile");
   uint32_t* const s_keys = s_img;
@@ -131,29 +135,54 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
     }
     s_img[idx] = v;
   }
-  if (tid == 0) s_cnt = 0;
+  if (tid == 0) { s_cnt = 0; s_nwork = 0; }
   __syncthreads();
 
   if (WRITE_SCORE || DETECT) {
-    // scores of the tile plus a ring (the 3x3 non-max suppression needs 1 pixel), one strip of 4 per item
-    for (int idx = tid; idx < SC_ROWS * SC_DW; idx += NTHREADS) {
-      const int sr = idx / SC_DW, ss = idx - sr * SC_DW;
-      const int gy = y0 - 1 + sr, gx = x0 - 4 + 4 * ss;
-      uint32_t packed = 0;
-      if (gy >= 3 && gy < H - 3 && gx + 3 >= 3 && gx < W - 3) {
-        uint32_t r[7][3];
+    // Pass 1 -- cheap necessary test on every pixel of the tile plus a ring (the 3x3 non-max
+    // suppression needs 1 pixel), one strip of 4 per item.  A 9-long arc of the 16-circle always
+    // contains one of N/S and one of E/W, so a corner needs  min(max(N,S), max(E,W)) > p + thr  or
+    // max(min(N,S), min(E,W)) < p - thr.  Survivors are compacted into an LDS work list (wave prefix
+    // sum with DPP, one LDS atomic per wave) so that pass 2 runs the full score on dense lanes.
+    for (int idx0 = 0; idx0 < SC_ROWS * SC_DW; idx0 += NTHREADS) {   // uniform trip count (wave scans inside)
+      const int idx = idx0 + tid;
+      int mask = 0;
+      if (idx < SC_ROWS * SC_DW) {
+        const int sr = idx / SC_DW, ss = idx - sr * SC_DW;
+        const int gy = y0 - 1 + sr, gx = x0 - 4 + 4 * ss;
+        if (gy >= 3 && gy < H - 3 && gx + 3 >= 3 && gx < W - 3) {
+          const uint32_t* cp = &s_img[(sr + 3) * IMG_DW + ss];
+          const uint32_t a = cp[0], b = cp[1], c = cp[2];
+          const uint32_t nn = s_img[sr * IMG_DW + ss + 1], so = s_img[(sr + 6) * IMG_DW + ss + 1];
+          const uint32_t wv = __builtin_amdgcn_alignbyte(b, a, 1);   // bytes x-3 of the 4 pixels
+          const uint32_t ev = __builtin_amdgcn_alignbyte(c, b, 3);   // bytes x+3
 #pragma unroll
-        for (int k = 0; k < 7; ++k)
-#pragma unroll
-          for (int j = 0; j < 3; ++j) r[k][j] = s_img[(sr + k) * IMG_DW + ss + j];
-        int sc[4] = {fast_score_strip<0>(r), fast_score_strip<1>(r), fast_score_strip<2>(r), fast_score_strip<3>(r)};
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool ok = sc[e] >= thr && gx + e >= 3 && gx + e < W - 3;
-          packed |= ok ? ((uint32_t)sc[e] << (8 * e)) : 0u;
+          for (int e = 0; e < 4; ++e) {
+            const int p = byte_of(b, e);
+            const int n_ = byte_of(nn, e), s_ = byte_of(so, e), w_ = byte_of(wv, e), e_ = byte_of(ev, e);
+            const int hi = min(max(n_, s_), max(e_, w_)), lo = max(min(n_, s_), min(e_, w_));
+            const bool cand = (hi > p + thr || lo < p - thr) && gx + e >= 3 && gx + e < W - 3;
+            mask |= cand ? (1 << e) : 0;
+          }
         }
+        s_score[idx] = 0u;
       }
-      s_score[idx] = packed;
+      const int cnt = __popc(mask);
+      int incl = cnt;   // inclusive wave scan (same DPP sequence as wave_sum_i32)
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xe, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xc, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, true);
+      incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, true);
+      const int total = __builtin_amdgcn_readlane(incl, 63);
+      int base = 0;
+      if ((tid & 63) == 0 && total > 0) base = atomicAdd(&s_nwork, total);
+      base = __builtin_amdgcn_readfirstlane(base);
+      int pos = base + incl - cnt;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (mask & (1 << e)) s_work[pos++] = (uint16_t)(idx * 4 + e);
     }
   }
   if (BLUR) {
@@ -177,6 +206,30 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
     }
   }
   __syncthreads();
+
+  if (WRITE_SCORE || DETECT) {
+    // Pass 2 -- exact FAST score of the survivors, one pixel per lane.  The 12-byte row windows are
+    // re-aligned with v_alignbyte so that the pixel sits at byte 4 and the strip code (E = 0) applies.
+    const int nwork = s_nwork;
+    uint8_t* score8 = reinterpret_cast<uint8_t*>(s_score);
+    for (int j = tid; j < nwork; j += NTHREADS) {
+      const int ent = s_work[j];
+      const int idx = ent >> 2, e = ent & 3;
+      const int sr = idx / SC_DW, ss = idx - sr * SC_DW;
+      uint32_t r[7][3];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const uint32_t* rp = &s_img[(sr + k) * IMG_DW + ss];
+        const uint32_t a = rp[0], b = rp[1], c = rp[2];
+        r[k][0] = __builtin_amdgcn_alignbyte(b, a, e);
+        r[k][1] = __builtin_amdgcn_alignbyte(c, b, e);
+        r[k][2] = c >> (8 * e);
+      }
+      const int sc = fast_score_strip<0>(r);
+      if (sc >= thr) score8[ent] = (uint8_t)sc;
+    }
+    __syncthreads();
+  }
 
   if (WRITE_SCORE) {
     for (int idx = tid; idx < TH * STRIPS; idx += NTHREADS) {
