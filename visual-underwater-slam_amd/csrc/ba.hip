@@ -440,10 +440,10 @@ __global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const d
 // Sband entry (i, s) is the 6x6 block (i, i - s), s in [0, band].
 //
 // Per panel three launches:
-//   chol_panel   ONE wave; lane R keeps row R of the 48x48 diagonal block in registers (the
-//                right-hand side rides along as row 48), 48 fully unrolled column steps, the
-//                pivot column is broadcast through a 49-entry LDS vector; no divides in the loop
-//                (v_rsq_f64 + two Newton steps);
+//   chol_panel   4 waves; lane R keeps row R of the 48x48 diagonal block in registers, split by
+//                columns over the waves (the right-hand side rides along as row 48), 48 fully
+//                unrolled column steps, the pivot column is broadcast through a double-buffered
+//                LDS vector (one barrier per step); no divides in the loop (v_rsq_f64 + Newton);
 //   chol_trsm    one scalar row of the window per lane, x[48] in registers, L_D broadcast from LDS;
 //   chol_update  SYRK of the window, 96x96 tiles, v_mfma_f64_16x16x4_f64 (K = 48): the only
 //                GEMM-shaped part of the path and where the factorisation's flops are.
@@ -471,61 +471,63 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
   return r;
 }
 
-__global__ __launch_bounds__(64) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
-                                                        double* __restrict__ yv, int* __restrict__ status) {
+// Four waves, lane R of every wave = row R of the 48x48 block (row 48 = the right-hand side riding
+// along); wave w keeps the columns C = 4j + w of its rows in registers, so the rank-1 update of a
+// column step is 12 FMAs per lane.  The pivot column travels through a double-buffered LDS vector:
+// one barrier per step.
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
+                                                         double* __restrict__ yv, int* __restrict__ status) {
   __shared__ double s_l[2][64];
-  const int lane = threadIdx.x;
+  __shared__ int s_bad;
+  constexpr int NJ = NB / 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
   const int R = lane;                 // rows 0..nb-1: block rows; row nb: the right-hand side
   const int ii = R / 6, rr = R - 6 * ii;
-  double row[NB];
+  if (threadIdx.x == 0) s_bad = 0x7FFFFFFF;
+  double row[NJ];
 #pragma unroll
-  for (int c = 0; c < NB; ++c) row[c] = 0.0;
-  if (R < nb) {
-#pragma unroll
-    for (int kk = 0; kk < PB; ++kk)
-      if (kk <= ii && ii - kk <= band) {
-        const double* b = blk_ptr(Sb, band, k0 + ii, k0 + kk) + 6 * rr;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) row[6 * kk + c] = b[c];
-      }
-  } else if (R == nb) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (c < nb) row[c] = yv[6 * (size_t)k0 + c];
+  for (int j = 0; j < NJ; ++j) {
+    const int C = 4 * j + wave, kk = C / 6, cc = C - 6 * kk;
+    double v = 0.0;
+    if (R < nb && kk <= ii && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * rr + cc];
+    if (R == nb && C < nb) v = yv[6 * (size_t)k0 + C];
+    row[j] = v;
   }
-  int bad = 0;
+  __syncthreads();
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    if (c < nb) {   // wave-uniform
-      double d = bcast_lane(row[c], c);
-      if (!(d > 0.0)) {
-        if (bad == 0) bad = 6 * k0 + c + 1;
-        d = 1.0;
+    if (c < nb) {   // uniform
+      if (wave == (c & 3)) {   // the wave that owns column c produces the pivot column
+        double d = bcast_lane(row[c >> 2], c);
+        if (!(d > 0.0)) {
+          if (lane == 0) atomicMin(&s_bad, 6 * k0 + c + 1);
+          d = 1.0;
+        }
+        const double rs = rsqrt_newton(d);
+        const double l = (R == c) ? d * rs : row[c >> 2] * rs;
+        row[c >> 2] = l;
+        s_l[c & 1][lane] = l;
       }
-      const double rs = rsqrt_newton(d);
-      const double l = (R == c) ? d * rs : row[c] * rs;
-      row[c] = l;
-      s_l[c & 1][lane] = l;
       __syncthreads();
+      const double lR = s_l[c & 1][lane];
 #pragma unroll
-      for (int C = c + 1; C < NB; ++C) row[C] -= l * s_l[c & 1][C];   // columns C > R only touch the unused upper part
+      for (int j = 0; j < NJ; ++j)
+        if (4 * j + 3 > c) {   // compile-time prune; columns C <= c of this wave are finished
+          const int C = 4 * j + wave;
+          if (C > c) row[j] -= lR * s_l[c & 1][C];   // columns C > R only touch the unused upper part
+        }
     }
   }
-  if (bad != 0 && lane == 0 && status[0] == 0) status[0] = bad;
-  if (R < nb) {
+  __syncthreads();
+  if (threadIdx.x == 0 && s_bad != 0x7FFFFFFF && status[0] == 0) status[0] = s_bad;
 #pragma unroll
-    for (int kk = 0; kk < PB; ++kk)
-      if (kk <= ii && ii - kk <= band) {
-        double* b = blk_ptr(Sb, band, k0 + ii, k0 + kk) + 6 * rr;
-#pragma unroll
-        for (int c = 0; c < 6; ++c) b[c] = (6 * kk + c <= R) ? row[6 * kk + c] : 0.0;   // strict upper part of the diagonal blocks = 0
-      }
-  } else if (R == nb) {
-#pragma unroll
-    for (int c = 0; c < NB; ++c)
-      if (c < nb) yv[6 * (size_t)k0 + c] = row[c];
+  for (int j = 0; j < NJ; ++j) {
+    const int C = 4 * j + wave, kk = C / 6, cc = C - 6 * kk;
+    if (R < nb && kk <= ii && ii - kk <= band)
+      blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * rr + cc] = (C <= R) ? row[j] : 0.0;   // strict upper part of the diagonal blocks = 0
+    if (R == nb && C < nb) yv[6 * (size_t)k0 + C] = row[j];
   }
 }
 
@@ -618,10 +620,15 @@ __global__ __launch_bounds__(TRSM_T) void chol_trsm_kernel(double* __restrict__ 
 }
 
 // Trailing update of the window (SYRK): A_ij -= X_i X_j^T for window poses j <= i, where X = the
-// panel columns just produced by chol_trsm.  One workgroup per 96x96 tile (16x16 poses) of the lower
-// triangle, 36 MFMA tiles of 16x16 shared by 4 waves, K = 48 = 12 steps of v_mfma_f64_16x16x4_f64.
+// panel columns just produced by chol_trsm.  One workgroup per UT x UT tile of the lower triangle,
+// (UT/16)^2 MFMA tiles of 16x16 shared by 4 waves, K = 48 = 12 steps of v_mfma_f64_16x16x4_f64.
 // The right-hand side rides along: y_i -= X_i y_panel (done by the diagonal tiles).
-constexpr int UT = 96;            // scalar rows per tile
+#ifndef VUS_UT
+#define VUS_UT 48
+#endif
+constexpr int UT = VUS_UT;        // scalar rows per tile (48 or 96)
+constexpr int UMT = UT / 16;      // MFMA tiles per side
+constexpr int UQ = (UMT * UMT + 3) / 4;   // MFMA tiles per wave
 constexpr int UTP = UT / 6;       // poses per tile
 constexpr int ULD = NB + 1;       // LDS row stride (doubles)
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -657,27 +664,27 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ S
   const int arow = lane & 15, kq = lane >> 4;
   // this wave's 9 MFMA tiles: accumulate X_i X_j^T - A and store the negation, so the old values
   // enter as the C operand (their loads overlap the LDS reads) instead of a read-modify-write tail
-  double4_t acc[9];
-  bool ok[9][4];
+  double4_t acc[UQ];
+  bool ok[UQ][4];
 #pragma unroll
-  for (int q = 0; q < 9; ++q) {
+  for (int q = 0; q < UQ; ++q) {
     const int t = wave + 4 * q;
-    const int a = t / 6, b = t - 6 * a;
+    const int a = t / UMT, b = t - UMT * a;
     const int Cc = 16 * b + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int Rr = 16 * a + (lane >> 4) + 4 * r;
       const int i = pi0 + Rr / 6, j = pj0 + Cc / 6;
-      ok[q][r] = i <= i_last && j <= i && (j < i || (Cc % 6) <= (Rr % 6));
+      ok[q][r] = t < UMT * UMT && i <= i_last && j <= i && (j < i || (Cc % 6) <= (Rr % 6));
       const double* src = ok[q][r] ? blk_ptr(Sb, band, i, j) + 6 * (Rr % 6) + (Cc % 6) : Sb;
       acc[q][r] = -*src;
     }
   }
 #pragma unroll
-  for (int q = 0; q < 9; ++q) {
+  for (int q = 0; q < UQ; ++q) {
     const int t = wave + 4 * q;
-    const int a = t / 6, b = t - 6 * a;
-    if (ti == tj && b > a) continue;             // strictly upper tiles of a diagonal workgroup
+    const int a = t / UMT, b = t - UMT * a;
+    if (t >= UMT * UMT || (ti == tj && b > a)) continue;   // strictly upper tiles of a diagonal workgroup
     const double* pa = Xi + (16 * a + arow) * ULD + kq;
     const double* pbm = Xj + (16 * b + arow) * ULD + kq;
 #pragma unroll
@@ -685,10 +692,10 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ S
   }
   // C/D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
-  for (int q = 0; q < 9; ++q) {
+  for (int q = 0; q < UQ; ++q) {
     const int t = wave + 4 * q;
-    const int a = t / 6, b = t - 6 * a;
-    if (ti == tj && b > a) continue;
+    const int a = t / UMT, b = t - UMT * a;
+    if (t >= UMT * UMT || (ti == tj && b > a)) continue;
     const int Cc = 16 * b + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -968,7 +975,7 @@ extern "C" int vus_ba_band_solve(double* Sband, int n_poses, int band, const dou
   VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
   negate_copy_kernel<<<cdiv(n, 256), 256, 0, st>>>(gs, dp, n);
   for (int k0 = 0; k0 < n_poses; k0 += PB) {
-    chol_panel_kernel<<<1, 64, 0, st>>>(Sband, n_poses, band, k0, dp, status);
+    chol_panel_kernel<<<1, 256, 0, st>>>(Sband, n_poses, band, k0, dp, status);
     const int pb = n_poses - k0 < PB ? n_poses - k0 : PB;
     const int i_first = k0 + pb;
     int i_last = k0 + pb - 1 + band;
