@@ -48,7 +48,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU (configs[1]: 1000)")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="bounded cpu_baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=64, help="bounded cpu_baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     return ap.parse_args()
@@ -95,12 +95,30 @@ def timed_stage_process(fe, images, events):
     events.append(ev)
 
 
+def measured_traffic(kernel, frames):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json: bytes per
+    image measured by tools/collect_profiles.sh with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
+    passes).  Returns None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    try:
+        t = json.load(open(path))
+        key = {"fast_detect": "fast_tile_kernel", "orient_rbrief": "orient_rbrief_kernel",
+               "select_topk": "select_topk_kernel", "hamming_stereo": "hamming_match_rows_kernel",
+               "hamming_track": "hamming_match_kernel"}[kernel]
+        per_img = t["bytes_per_image"][key]
+        return int((per_img["fetch"] + per_img["write"]) * 2 * frames)
+    except Exception:
+        return None
+
+
 def cpu_baseline(n_frames, t0):
     """The C oracle ("port") on the first n_frames of the same stream, all host cores."""
     import numpy as np
     from visual_underwater_slam_amd import synth
     from oracle import oracle as O
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     O.lib().vus_oracle_set_threads(cores)
     img = synth.stereo_frames(t0, n_frames).reshape(2 * n_frames, H, W)
     t = time.perf_counter()
@@ -114,6 +132,36 @@ def cpu_baseline(n_frames, t0):
     return {"value": round(n_frames / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": f"first {n_frames} stereo frames of the same synthetic stream, C oracle "
                       f"(gcc -O2, OpenMP over images), {dt:.2f} s"}
+
+
+def ba_cpu_baseline(device):
+    """The C oracle's LM (single thread, "port") against the GPU solver on a bounded BA problem
+    (400 keyframes / 10k landmarks / 400 observations per keyframe): the full configs[2] problem would
+    keep one CPU core busy for minutes."""
+    import numpy as np
+    from visual_underwater_slam_amd import synth, ba_pack
+    from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
+    from oracle import oracle as O
+    n_kf, n_lm, obs = 400, 10000, 400
+    s = synth.ba_sequence(n_kf, n_lm, obs)
+    nL = len(s["points_gt"])
+    pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"]), torch.from_numpy(s["obs_point"]),
+                                   torch.from_numpy(s["meas"]), n_kf, nL)
+    st = ba_pack.build_structure(pk)
+    P = O.BAProblem(pk, s["K"], s["sigma"], (np.array([0], np.int32), s["poses_gt"][:1], s["prior_sigmas"][None]))
+    t = time.perf_counter()
+    _, _, rep = O.ba_lm_optimize(P, st["band"], s["poses_init"], s["points_init"])
+    cpu_s = time.perf_counter() - t
+    prob = StereoBAProblem(s["obs_pose"], s["obs_point"], s["meas"], n_kf, nL, s["K"], s["sigma"], prior_pose=[0],
+                           prior_T=s["poses_gt"][:1], prior_sigmas=s["prior_sigmas"][None], device=device)
+    sv = StereoBASolver(prob)
+    p0, x0 = torch.from_numpy(s["poses_init"]).to(device), torch.from_numpy(s["points_init"]).to(device)
+    sv.optimize(p0, x0)
+    _, _, grep = sv.optimize(p0, x0)
+    return {"value": round(cpu_s, 3), "unit": "s", "cores": 1, "kind": "port",
+            "sample": f"full LM on {n_kf} keyframes / {nL} landmarks / {prob.n_obs} stereo factors (band {prob.band}), "
+                      f"C oracle gcc -O2, {rep['tries']} linear solves",
+            "gpu_same_problem_s": round(grep.seconds, 4), "gpu_speedup": round(cpu_s / grep.seconds, 1)}
 
 
 def main():
@@ -160,6 +208,7 @@ def main():
     stage_ms = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in events) / len(events) for i, n in enumerate(names)}
     dom = max(stage_ms, key=stage_ms.get)
     achieved = ALGO_BYTES[dom] * F / (stage_ms[dom] * 1e-3) / 1e9
+    traffic = measured_traffic(dom, F)
     out = {
         "metric": "ORB detect+match frames/sec", "value": round(world * F * a.steps / dt, 2),
         "unit": "stereo frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -172,7 +221,11 @@ def main():
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "pipeline_GBps": round(ALGO_BYTES_FRAME * F * a.steps / dt / 1e9 * world, 2),
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
-                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None},
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
+                     "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * F,
+                     "note": "fast_detect is VALU-issue bound (integer min/max/SDWA ops issue at 0.57x the fp32 "
+                             "rate, profiles/valu_issue_rates_*.txt); traffic = FETCH_SIZE+WRITE_SIZE of a separate "
+                             "rocprofv3 --pmc run (profiles/traffic.json), scaled to this launch"},
     }
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
@@ -182,6 +235,8 @@ def main():
             del fe, images
             torch.cuda.empty_cache()
             out["ba"] = ba_bench.run(device)
+            if not a.no_cpu_baseline:
+                out["ba"]["cpu_baseline"] = ba_cpu_baseline(device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -18,7 +18,7 @@ pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_IN
 pmc sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
-python3 $ROOT/tools/summarize_pmc.py /tmp/pmc_sq1 /tmp/pmc_sq2 /tmp/pmc_fetch /tmp/pmc_write > $OUT/pmc_frontend_${TAG}.txt || true
+python3 $ROOT/tools/summarize_pmc.py /tmp/pmc_sq1 /tmp/pmc_sq2 /tmp/pmc_fetch /tmp/pmc_write --traffic-json $OUT/traffic.json 400 > $OUT/pmc_frontend_${TAG}.txt || true
 # 4. BA kernels: stats + MFMA counters
 rm -rf /tmp/prof_ba && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ba -- python3 $ROOT/tools/ba_profile.py > /dev/null 2>&1 || true
 python3 $ROOT/tools/summarize_stats.py /tmp/prof_ba 40 | grep -v "at::native\|rocprim\|rocclr\|compute_cuda" > $OUT/kernel_stats_ba_${TAG}.txt || true

@@ -2,7 +2,7 @@
 """Summarise rocprofv3 --pmc CSV output: per kernel, mean counter value per dispatch."""
 import csv, glob, sys, collections, re
 out = collections.defaultdict(lambda: collections.defaultdict(list))
-for d in sys.argv[1:]:
+for d in [a for a in sys.argv[1:] if a.startswith("/") or a.startswith("gpurun") or a.startswith(".")]:
     for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
@@ -15,3 +15,20 @@ for k, cs in out.items():
     print(k)
     for c, v in sorted(cs.items()):
         print(f"   {c:28s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
+
+# optional: --traffic-json <path> <n_images>  -> bytes per image per kernel from FETCH_SIZE / WRITE_SIZE (KB)
+if "--traffic-json" in sys.argv:
+    import json
+    i = sys.argv.index("--traffic-json")
+    path, n_img = sys.argv[i + 1], int(sys.argv[i + 2])
+    res = {}
+    for k, cs in out.items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            kk = k.split("<")[0]
+            f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024 / n_img
+            w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024 / n_img
+            res[kk] = {"fetch": f, "write": w}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --frames %d" % (n_img // 2),
+               "note": "FETCH_SIZE taken as reported (4-byte-per-lane loads; the 2x correction of MI355X_MICROARCH.md "
+                       "applies to 16-byte-per-lane streaming reads); hamming kernels: per image = per pair",
+               "bytes_per_image": res}, open(path, "w"), indent=1)
