@@ -169,14 +169,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # VUS_BENCH_BACKEND=gloo + several ranks on ONE GPU is a rehearsal of the multi-rank code path only
+    backend = os.environ.get("VUS_BENCH_BACKEND", "nccl")
+    dev_index = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
+    device = torch.device("cuda", dev_index)
+    torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)
+        else:
+            dist.init_process_group(backend)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
 
     from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
     F = a.frames
@@ -200,7 +205,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
