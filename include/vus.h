@@ -88,6 +88,23 @@ int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, const int* 
                       int max_dy, int min_disp, int max_disp, int max_dist,
                       int32_t* idx_out, int32_t* dist_out, void* stream);
 
+/* CameraMeasurement emitter (what batch.py:149-154 reads from the nodelet's message): persistent
+ * feature ids propagated along the left(t)->left(t+1) matches, and the features' normalised image
+ * coordinates.  Frame f's left image is image 2f, its right image 2f+1 (as in vus_hamming_match).
+ *   stereo_idx [n_frames, max_kp]   left->right match of frame f (-1: none)
+ *   track_idx  [n_frames-1, max_kp] left(f)->left(f+1) match (-1: none); may be NULL when n_frames == 1
+ * A left keypoint j of frame f inherits the id of the lowest-index keypoint of frame f-1 whose track
+ * match is j (if that keypoint carries an id); stereo-matched keypoints without an id get fresh ids
+ * in index order.  Keypoints without a stereo match keep an inherited id for later frames but are
+ * not published.
+ *   ids_out  int64 [n_frames, max_kp]   id of every PUBLISHED feature, -1 otherwise
+ *   feat_out f64   [n_frames, max_kp, 4] (u0, v0, u1, v1) = 2*x/W - 1, 2*y/H - 1 for both cameras
+ *                  (zeros where not published)
+ *   n_ids_out int64 [1]                 number of ids issued */
+int vus_track_ids(const int32_t* stereo_idx, const int32_t* track_idx, const uint32_t* kp_keys,
+                  const int* kp_count, int n_frames, int max_kp, int H, int W, int64_t* ids_out,
+                  double* feat_out, int64_t* n_ids_out, void* stream);
+
 /* get_landmarks of batch.py:144-176, elementwise over n features (fp64):
  *   feat [n,4] = (u0, v0, u1, v1) normalised image coordinates of the CameraMeasurement message,
  *   cam  [8]   = (fx, fy, cx, cy, baseline, resolution_x, resolution_y, unused),

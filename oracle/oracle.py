@@ -112,6 +112,18 @@ def hamming_match(desc, kp_keys, kp_count, W, q_index, t_index, max_dy=-1, min_d
     return idx, dist
 
 
+def track_ids(stereo_idx, track_idx, kp_keys, kp_count, H, W):
+    stereo_idx = np.ascontiguousarray(stereo_idx, np.int32)
+    F, K = stereo_idx.shape
+    track_idx = np.ascontiguousarray(track_idx, np.int32) if track_idx is not None and F > 1 else None
+    kp_keys = np.ascontiguousarray(kp_keys, np.uint32)
+    kp_count = np.ascontiguousarray(kp_count, np.int32)
+    ids = np.empty((F, K), np.int64); feat = np.empty((F, K, 4), np.float64); n = np.zeros(1, np.int64)
+    _check(lib().vus_track_ids_cpu(_p(stereo_idx), _p(track_idx), _p(kp_keys), _p(kp_count), F, K, int(H), int(W),
+                                   _p(ids), _p(feat), _p(n)), "track_ids")
+    return ids, feat, int(n[0])
+
+
 def triangulate(feat, cam, Rt):
     feat = np.ascontiguousarray(feat, np.float64)
     cam = np.ascontiguousarray(cam, np.float64)

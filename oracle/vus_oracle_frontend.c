@@ -243,6 +243,52 @@ int vus_hamming_match_cpu(const uint64_t* desc, const uint32_t* kp_keys, const i
   return VUS_OK;
 }
 
+/* CameraMeasurement emitter: ids along the temporal matches, frame by frame (see include/vus.h). */
+int vus_track_ids_cpu(const int32_t* stereo_idx, const int32_t* track_idx, const uint32_t* kp_keys,
+                      const int* kp_count, int n_frames, int max_kp, int H, int W, int64_t* ids_out,
+                      double* feat_out, int64_t* n_ids_out) {
+  if (!stereo_idx || !kp_keys || !kp_count || !ids_out || !feat_out || !n_ids_out || n_frames < 0 || max_kp < 1 ||
+      H < 1 || W < 1 || (n_frames > 1 && !track_idx))
+    return VUS_E_INVALID;
+  int64_t* cur = (int64_t*)malloc(sizeof(int64_t) * (size_t)max_kp);
+  int64_t* nxt = (int64_t*)malloc(sizeof(int64_t) * (size_t)max_kp);
+  int64_t next_id = 0;
+  int n_prev = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    int nl = kp_count[2 * f] < max_kp ? kp_count[2 * f] : max_kp;
+    int nr = kp_count[2 * f + 1] < max_kp ? kp_count[2 * f + 1] : max_kp;
+    for (int i = 0; i < max_kp; ++i) nxt[i] = -1;
+    if (f > 0)
+      for (int ip = 0; ip < n_prev; ++ip) {
+        int j = track_idx[(size_t)(f - 1) * max_kp + ip];
+        if (j >= 0 && j < nl && cur[ip] >= 0 && nxt[j] < 0) nxt[j] = cur[ip];
+      }
+    const uint32_t* kl = kp_keys + (size_t)(2 * f) * max_kp;
+    const uint32_t* kr = kp_keys + (size_t)(2 * f + 1) * max_kp;
+    for (int i = 0; i < max_kp; ++i) {
+      int64_t* id = ids_out + (size_t)f * max_kp + i;
+      double* ft = feat_out + ((size_t)f * max_kp + i) * 4;
+      *id = -1;
+      ft[0] = ft[1] = ft[2] = ft[3] = 0.0;
+      if (i >= nl) continue;
+      int j = stereo_idx[(size_t)f * max_kp + i];
+      if (j < 0 || j >= nr) continue;
+      if (nxt[i] < 0) nxt[i] = next_id++;
+      *id = nxt[i];
+      uint32_t pl = kl[i] & VUS_KEY_POS_MASK, pr = kr[j] & VUS_KEY_POS_MASK;
+      ft[0] = 2.0 * (double)(pl % (uint32_t)W) / (double)W - 1.0;
+      ft[1] = 2.0 * (double)(pl / (uint32_t)W) / (double)H - 1.0;
+      ft[2] = 2.0 * (double)(pr % (uint32_t)W) / (double)W - 1.0;
+      ft[3] = 2.0 * (double)(pr / (uint32_t)W) / (double)H - 1.0;
+    }
+    memcpy(cur, nxt, sizeof(int64_t) * (size_t)max_kp);
+    n_prev = nl;
+  }
+  n_ids_out[0] = next_id;
+  free(cur); free(nxt);
+  return VUS_OK;
+}
+
 /* batch.py:152-166, one feature at a time, in double precision, same operation order. */
 int vus_triangulate_cpu(const double* feat, int n, const double* cam, const double* Rt, double* out) {
   if (!feat || !cam || !Rt || !out || n < 0) return VUS_E_INVALID;

@@ -267,3 +267,32 @@ def test_full_frontend_pipeline_matches_oracle_chain(gpu, oracle):
     assert -1.0 <= ft.u0 <= 1.0 and -1.0 <= ft.v1 <= 1.0 and ft.id >= 0
     ids0 = {f_.id for f_ in msgs[0].features}
     assert len(ids0 & {f_.id for f_ in msgs[1].features}) > 50   # tracks persist across frames
+
+
+def test_track_ids_matches_oracle_and_feeds_get_landmarks(gpu, oracle):
+    """vus_track_ids on the GPU == oracle; its features go through vus_triangulate (batch.py:144-176)."""
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams, triangulate
+    F, H, W = 6, 360, 640
+    img = synth.stereo_frames(200, F, H=H, W=W)
+    fe = StereoOrbFrontend(H, W, max_frames=F, params=ImageProcessorParams(max_features=800))
+    res = fe.process(torch.from_numpy(img).cuda())
+    ids, feats, n_ids = fe.feature_tracks(res)
+    torch.cuda.synchronize()
+    eids, efeat, en = oracle.track_ids(res.stereo_idx.cpu().numpy(), res.track_idx.cpu().numpy(),
+                                       res.kp_keys.cpu().numpy().view(np.uint32), res.kp_count.cpu().numpy(), H, W)
+    assert n_ids == en and np.array_equal(ids.cpu().numpy(), eids)
+    assert np.array_equal(feats.cpu().numpy(), efeat)
+    pub = eids >= 0
+    assert pub.sum() > 500 and len(set(eids[0][pub[0]].tolist())) == pub[0].sum()      # unique per frame
+    persisted = len(set(eids[0][pub[0]].tolist()) & set(eids[1][pub[1]].tolist()))
+    assert persisted > 50
+    msgs = fe.camera_measurements(res)
+    assert [len(m.features) for m in msgs] == pub.sum(1).tolist()
+    # feed the published features of frame 0 through get_landmarks on the GPU
+    cam = torch.tensor([1827.0, 1827.5999755859375, 968.9000244140625, 561.4000244140625, 0.063, 1920, 1080, 0],
+                       dtype=torch.float64, device="cuda")
+    Rt = torch.tensor([1.0, 0, 0, 0, 1, 0, 0, 0, 1, 0.5, -0.25, 2.0], dtype=torch.float64, device="cuda")
+    f0 = feats[0][ids[0] >= 0].contiguous()
+    lm = triangulate(f0, cam, Rt).cpu().numpy()
+    exp = oracle.triangulate(f0.cpu().numpy(), cam.cpu().numpy(), Rt.cpu().numpy())
+    assert np.array_equal(lm, exp)

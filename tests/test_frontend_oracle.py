@@ -278,3 +278,34 @@ def test_orb_tables_match_regeneration():
     dx, dy = gen.disc_offsets()
     assert np.array_equal(arr("VUS_DISC_DX"), dx) and np.array_equal(arr("VUS_DISC_DY"), dy)
     assert len(dx) == 749 and max(np.hypot(dx, dy)) < 15.9
+
+
+def test_track_ids_semantics(oracle):
+    """3 frames, 4 slots: inheritance via the lowest-index predecessor, fresh ids in index order,
+    unpublished keypoints keep their id for later frames."""
+    W, H, K = 100, 80, 4
+    keys = np.zeros((6, K), np.uint32)
+    for n in range(6):
+        for i in range(K):
+            keys[n, i] = (10 + 5 * i + n) * W + (20 + 7 * i)
+    cnt = np.array([4, 4, 3, 4, 4, 2], np.int32)
+    stereo = np.array([[0, -1, 2, 3],      # frame 0: kp1 has no stereo match
+                       [1, 0, -1, 3],      # frame 1 (only 3 left kps: slot 3 ignored)
+                       [0, 1, 3, -1]], np.int32)   # frame 2: right image has 2 kps -> j=3 is invalid
+    track = np.array([[1, 0, 0, -1],       # f0->f1: kp0->1, kp1->0, kp2->0 (kp1 wins: lower index... but kp1 has no id!)
+                      [2, 2, 0, -1]], np.int32)    # f1->f2: kp0->2, kp1->2 (kp0 wins), kp2->0
+    ids, feat, n = oracle.track_ids(stereo, track, keys, cnt, H, W)
+    # frame 0: ids 0,1,2 to kp0,kp2,kp3
+    assert ids[0].tolist() == [0, -1, 1, 2]
+    # frame 1: kp1 <- kp0 (id 0); kp0 <- lowest predecessor index with an id mapping to 0: kp1 (ip=1) carries
+    # no id, kp2 (ip=2) carries id 1 -> inherits 1.  kp2 has no stereo match -> not published.
+    assert ids[1].tolist() == [1, 0, -1, -1]
+    # frame 2: kp2 <- kp0 of frame 1 (id 1); kp0 <- kp2 of frame 1 which carries no id -> fresh id 3;
+    # kp1 fresh id 4; kp2's stereo index 3 is out of range -> unpublished
+    assert ids[2].tolist() == [3, 4, -1, -1] and n == 5
+    x0, y0 = 20, 10
+    assert np.isclose(feat[0, 0, 0], 2 * x0 / W - 1) and np.isclose(feat[0, 0, 1], 2 * y0 / H - 1)
+    assert (feat[0, 1] == 0).all()
+    # batch.py:152-154 maps the normalised coordinates back to pixels of ITS resolution convention
+    uL = (feat[0, 0, 0] + 1) * 0.5 * W
+    assert np.isclose(uL, x0)

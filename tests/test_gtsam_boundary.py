@@ -182,3 +182,17 @@ def test_product_needs_gpu_no_cpu_fallback():
     graph, initial = mini_batch_create(seq)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         gtsam.LevenbergMarquardtOptimizer(graph, initial, gtsam.LevenbergMarquardtParams()).optimize()
+
+
+def test_reporting_helpers_follow_batch_py():
+    from visual_underwater_slam_amd import report
+    v = Values()
+    rng = np.random.default_rng(0)
+    pos = rng.normal(size=(5, 3))
+    for i in range(5):
+        v.insert(X(i), Pose3(Rot3(), pos[i]))
+    pts = report.constr3DPoints(v)                       # batch.py:57-68
+    assert pts.shape == (6, 3) and np.allclose(pts[1:], pos)
+    odom = pos + np.array([0.0, 0.0, 0.7433])            # batch.py:363
+    assert report.trajectory_mse(pts, odom) < 1e-30
+    assert np.isclose(report.trajectory_mse(pts, odom + 0.1), 0.01)

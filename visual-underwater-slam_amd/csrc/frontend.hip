@@ -752,6 +752,90 @@ __global__ __launch_bounds__(256) void hamming_match_rows_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// CameraMeasurement emitter: persistent ids along the temporal matches.  Frames are inherently
+// sequential (ids of frame f depend on frame f-1), so ONE workgroup walks the frames; inside a frame
+// everything is parallel over keypoints (LDS atomicMin picks the lowest-index predecessor, a block
+// scan numbers the fresh ids in index order).
+constexpr int TRK_THREADS = 1024;
+__global__ __launch_bounds__(TRK_THREADS) void track_ids_kernel(
+    const int32_t* __restrict__ stereo_idx, const int32_t* __restrict__ track_idx,
+    const uint32_t* __restrict__ kp_keys, const int* __restrict__ kp_count, int n_frames, int max_kp, int H, int W,
+    long long* __restrict__ ids_out, double* __restrict__ feat_out, long long* __restrict__ n_ids_out) {
+  extern __shared__ long long s_trk[];
+  long long* s_cur = s_trk;                    // [max_kp] ids carried by the previous frame's keypoints
+  long long* s_nxt = s_trk + max_kp;           // [max_kp]
+  int* s_src = reinterpret_cast<int*>(s_trk + 2 * max_kp);   // [max_kp] lowest predecessor index
+  __shared__ int s_part[TRK_THREADS];
+  __shared__ long long s_next;
+  const int tid = threadIdx.x;
+  const int per = (max_kp + TRK_THREADS - 1) / TRK_THREADS;   // consecutive keypoints per thread
+  if (tid == 0) s_next = 0;
+  int n_prev = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    const int nl = min(kp_count[2 * f], max_kp), nr = min(kp_count[2 * f + 1], max_kp);
+    for (int i = tid; i < max_kp; i += TRK_THREADS) { s_nxt[i] = -1; s_src[i] = 0x7FFFFFFF; }
+    __syncthreads();
+    if (f > 0)
+      for (int ip = tid; ip < n_prev; ip += TRK_THREADS) {
+        const int j = track_idx[(size_t)(f - 1) * max_kp + ip];
+        if (j >= 0 && j < nl && s_cur[ip] >= 0) atomicMin(&s_src[j], ip);
+      }
+    __syncthreads();
+    for (int j = tid; j < nl; j += TRK_THREADS)
+      if (s_src[j] != 0x7FFFFFFF) s_nxt[j] = s_cur[s_src[j]];
+    __syncthreads();
+    // fresh ids in index order: thread t owns keypoints [t*per, (t+1)*per)
+    int local = 0;
+    for (int u = 0; u < per; ++u) {
+      const int i = tid * per + u;
+      if (i < nl) {
+        const int j = stereo_idx[(size_t)f * max_kp + i];
+        local += (j >= 0 && j < nr && s_nxt[i] < 0) ? 1 : 0;
+      }
+    }
+    s_part[tid] = local;
+    __syncthreads();
+    for (int o = 1; o < TRK_THREADS; o <<= 1) {   // inclusive Hillis-Steele scan
+      const int v = tid >= o ? s_part[tid - o] : 0;
+      __syncthreads();
+      s_part[tid] += v;
+      __syncthreads();
+    }
+    long long id = s_next + s_part[tid] - local;
+    const long long total = s_part[TRK_THREADS - 1];
+    const uint32_t* kl = kp_keys + (size_t)(2 * f) * max_kp;
+    const uint32_t* kr = kp_keys + (size_t)(2 * f + 1) * max_kp;
+    for (int u = 0; u < per; ++u) {
+      const int i = tid * per + u;
+      if (i >= max_kp) break;
+      long long out_id = -1;
+      double ft[4] = {0.0, 0.0, 0.0, 0.0};
+      if (i < nl) {
+        const int j = stereo_idx[(size_t)f * max_kp + i];
+        if (j >= 0 && j < nr) {
+          if (s_nxt[i] < 0) s_nxt[i] = id++;
+          out_id = s_nxt[i];
+          const uint32_t pl = kl[i] & VUS_KEY_POS_MASK, pr = kr[j] & VUS_KEY_POS_MASK;
+          ft[0] = 2.0 * (double)(pl % (uint32_t)W) / (double)W - 1.0;
+          ft[1] = 2.0 * (double)(pl / (uint32_t)W) / (double)H - 1.0;
+          ft[2] = 2.0 * (double)(pr % (uint32_t)W) / (double)W - 1.0;
+          ft[3] = 2.0 * (double)(pr / (uint32_t)W) / (double)H - 1.0;
+        }
+      }
+      ids_out[(size_t)f * max_kp + i] = out_id;
+      double* o = feat_out + ((size_t)f * max_kp + i) * 4;
+      o[0] = ft[0]; o[1] = ft[1]; o[2] = ft[2]; o[3] = ft[3];
+    }
+    __syncthreads();
+    for (int i = tid; i < max_kp; i += TRK_THREADS) s_cur[i] = s_nxt[i];
+    if (tid == 0) s_next += total;
+    n_prev = nl;
+    __syncthreads();
+  }
+  if (tid == 0) n_ids_out[0] = s_next;
+}
+
+// ---------------------------------------------------------------------------------------------
 // get_landmarks (batch.py:152-166), one feature per thread, fp64, no FMA contraction
 // (this file is built with -ffp-contract=off so the result is bit-identical to the scalar order).
 __global__ void triangulate_kernel(const double* __restrict__ feat, int n, const double* __restrict__ cam,
@@ -886,6 +970,24 @@ extern "C" int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, 
                                                                 idx_out, dist_out);
   }
   VUS_CHECK_LAUNCH("hamming_match");
+  return VUS_OK;
+}
+
+extern "C" int vus_track_ids(const int32_t* stereo_idx, const int32_t* track_idx, const uint32_t* kp_keys,
+                             const int* kp_count, int n_frames, int max_kp, int H, int W, int64_t* ids_out,
+                             double* feat_out, int64_t* n_ids_out, void* stream) {
+  VUS_REQUIRE(stereo_idx && kp_keys && kp_count && ids_out && feat_out && n_ids_out, "null buffer");
+  VUS_REQUIRE(n_frames >= 0 && max_kp >= 1 && max_kp <= 8192 && H >= 1 && W >= 1, "n_frames=%d max_kp=%d H=%d W=%d",
+              n_frames, max_kp, H, W);
+  VUS_REQUIRE(n_frames <= 1 || track_idx != nullptr, "track_idx is null");
+  const size_t lds = (size_t)max_kp * (2 * sizeof(long long) + sizeof(int));
+  if (lds > 48 * 1024)
+    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(track_ids_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  track_ids_kernel<<<1, TRK_THREADS, lds, vus::as_stream(stream)>>>(
+      stereo_idx, track_idx, kp_keys, kp_count, n_frames, max_kp, H, W, reinterpret_cast<long long*>(ids_out), feat_out,
+      reinterpret_cast<long long*>(n_ids_out));
+  VUS_CHECK_LAUNCH("track_ids");
   return VUS_OK;
 }
 

@@ -140,38 +140,33 @@ class StereoOrbFrontend:
                                 f"{self.p.cand_cap}: raise ImageProcessorParams.cand_cap")
 
     # ------------------------------------------------------------------------------------------
+    def feature_tracks(self, res: FrontendResult):
+        """GPU CameraMeasurement emitter (vus_track_ids): returns (ids int64 [F,K], feats f64 [F,K,4],
+        n_ids).  ids[f,i] >= 0 marks a published feature of frame f with persistent id; feats holds its
+        (u0, v0, u1, v1) in the normalised convention that batch.py:152-154 maps back to pixels."""
+        F, K = res.n_frames, self.p.max_features
+        dev = self.device
+        ids = torch.empty((F, K), dtype=torch.int64, device=dev)
+        feats = torch.empty((F, K, 4), dtype=torch.float64, device=dev)
+        n_ids = torch.zeros((1,), dtype=torch.int64, device=dev)
+        ptr = _lib.ptr
+        _lib.call("vus_track_ids", ptr(res.stereo_idx), ptr(res.track_idx) if F > 1 else None, ptr(res.kp_keys),
+                  ptr(res.kp_count), F, K, self.H, self.W, ptr(ids), ptr(feats), ptr(n_ids),
+                  _lib.current_stream_ptr())
+        return ids, feats, int(n_ids.item())
+
     def camera_measurements(self, res: FrontendResult) -> List[CameraMeasurement]:
-        """Per frame, the stereo-matched features as CameraMeasurement records with persistent ids
-        propagated along the left(t)->left(t+1) matches (normalised coordinates, so that
-        batch.py:152-154 maps them back to pixels of its 1920x1080 convention)."""
-        F, W, H = res.n_frames, self.W, self.H
-        x, y, _ = (t.cpu().numpy() for t in res.keypoints_xy_score())
-        sidx = res.stereo_idx.cpu().numpy()
-        tidx = res.track_idx.cpu().numpy() if F > 1 else None
-        cnt = res.kp_count.cpu().numpy()
-        out, next_id, prev_ids = [], 0, None
-        for f in range(F):
-            nl = int(cnt[2 * f])
-            ids = [-1] * nl
-            if prev_ids is not None:
-                for i_prev, j in enumerate(tidx[f - 1][:len(prev_ids)]):
-                    if j >= 0 and j < nl and prev_ids[i_prev] >= 0 and ids[j] < 0:
-                        ids[j] = prev_ids[i_prev]
+        """Per frame, the published features as CameraMeasurement records (message shape of
+        batch.py:149-154), built from feature_tracks()."""
+        ids, feats, _ = self.feature_tracks(res)
+        ids, feats = ids.cpu().numpy(), feats.cpu().numpy()
+        out = []
+        for f in range(res.n_frames):
             msg = CameraMeasurement()
-            for i in range(nl):
-                j = int(sidx[f][i])
-                if j < 0:
-                    ids[i] = -1 if ids[i] < 0 else ids[i]
-                    continue
-                if ids[i] < 0:
-                    ids[i] = next_id
-                    next_id += 1
-                msg.features.append(Feature(
-                    id=ids[i],
-                    u0=2.0 * float(x[2 * f][i]) / W - 1.0, v0=2.0 * float(y[2 * f][i]) / H - 1.0,
-                    u1=2.0 * float(x[2 * f + 1][j]) / W - 1.0, v1=2.0 * float(y[2 * f + 1][j]) / H - 1.0))
+            for i in (ids[f] >= 0).nonzero()[0].tolist():
+                u0, v0, u1, v1 = feats[f, i]
+                msg.features.append(Feature(id=int(ids[f, i]), u0=float(u0), v0=float(v0), u1=float(u1), v1=float(v1)))
             out.append(msg)
-            prev_ids = ids
         return out
 
 
