@@ -276,3 +276,44 @@ def pose_local(T, T2):
     xi = np.zeros(6)
     lib().vus_pose_local_cpu(_p(_f64(T)), _p(_f64(T2)), _p(xi))
     return xi
+
+
+# ---------------------------------------------------------------------------------------------
+# inertial / velocity factors (oracle/vus_oracle_nav.c)
+PIM = dict(DT=0, DR=1, DP=10, DV=13, DR_DBG=16, DP_DBA=25, DP_DBG=34, DV_DBA=43, DV_DBG=52, BIAS=61, COV=67, N=148)
+
+
+def imu_preintegrate(samples, bias_hat, acc_cov, gyro_cov, int_cov):
+    samples = _f64(np.asarray(samples).reshape(-1, 7))
+    pim = np.zeros(PIM["N"])
+    _check(lib().vus_imu_preintegrate_cpu(_p(samples), samples.shape[0], _p(_f64(bias_hat)), _p(_f64(acc_cov)),
+                                          _p(_f64(gyro_cov)), _p(_f64(int_cov)), _p(pim)), "imu_preintegrate")
+    return pim
+
+
+def sqrt_information(cov):
+    cov = _f64(cov)
+    n = cov.shape[0]
+    W = np.zeros((n, n))
+    _check(lib().vus_sqrt_information_cpu(_p(cov), n, _p(W)), "sqrt_information")
+    return W
+
+
+def imu_factor(Ti, vi, Tj, vj, bias, pim, g, jac=True):
+    r = np.zeros(9)
+    J = np.zeros((9, 24)) if jac else None
+    lib().vus_imu_factor_cpu(_p(_f64(Ti)), _p(_f64(vi)), _p(_f64(Tj)), _p(_f64(vj)), _p(_f64(bias)), _p(_f64(pim)),
+                             _p(_f64(g)), _p(r), _p(J))
+    return (r, J) if jac else r
+
+
+def dvl_factor(T, v, m):
+    e = np.zeros(3); JX = np.zeros((3, 6)); Jv = np.zeros((3, 3))
+    lib().vus_dvl_factor_cpu(_p(_f64(T)), _p(_f64(v)), _p(_f64(m)), _p(e), _p(JX), _p(Jv))
+    return e, JX, Jv
+
+
+def so3_expmap(w):
+    R = np.zeros(9)
+    lib().vus_so3_expmap_cpu(_p(_f64(w)), _p(R))
+    return R.reshape(3, 3)

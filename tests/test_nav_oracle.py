@@ -1,0 +1,126 @@
+"""Pins the oracle's inertial / velocity factors: preintegration
+against first principles, ImuFactor and DVL Jacobians against central differences."""
+import numpy as np
+import pytest
+
+G = np.array([0.0, 0.0, -9.81])          # PreintegrationParams.MakeSharedU(9.81), batch.py:181
+ACC_COV = np.eye(3) * 8.999999999999999e-08      # batch.py:183
+GYRO_COV = np.eye(3) * 1.2184696791468346e-07    # batch.py:184
+INT_COV = np.eye(3) * 1e-07                      # batch.py:185
+
+
+def rand_pose(rng, scale=1.0):
+    A = rng.normal(size=(3, 3)); Q, _ = np.linalg.qr(A)
+    if np.linalg.det(Q) < 0:
+        Q[:, 0] *= -1
+    return np.concatenate([Q.reshape(-1), scale * rng.normal(size=3)])
+
+
+def samples_const(acc, omega, n, dt=0.005):
+    return np.tile(np.concatenate([acc, omega, [dt]]), (n, 1))
+
+
+def test_preintegration_of_constant_motion(oracle):
+    P = oracle.PIM
+    # pure rotation at constant rate: dR = Exp(omega * T), no specific force -> dP = dV = 0
+    om = np.array([0.3, -0.2, 0.5])
+    pim = oracle.imu_preintegrate(samples_const(np.zeros(3), om, 40), np.zeros(6), ACC_COV, GYRO_COV, INT_COV)
+    assert np.isclose(pim[P["DT"]], 0.2)
+    assert np.allclose(pim[P["DR"]:P["DR"] + 9].reshape(3, 3), oracle.so3_expmap(om * 0.2), atol=1e-13)
+    assert np.allclose(pim[P["DP"]:P["DP"] + 6], 0)
+    # constant specific force, no rotation: dV = a T, dP = a T^2 / 2 exactly
+    a = np.array([0.4, -1.0, 9.81])
+    pim = oracle.imu_preintegrate(samples_const(a, np.zeros(3), 40), np.zeros(6), ACC_COV, GYRO_COV, INT_COV)
+    assert np.allclose(pim[P["DV"]:P["DV"] + 3], a * 0.2, rtol=1e-13)
+    assert np.allclose(pim[P["DP"]:P["DP"] + 3], 0.5 * a * 0.2 ** 2, rtol=1e-12)
+    # the bias estimate is subtracted from the raw measurements
+    b = np.array([0.01, -0.02, 0.03, 0.001, 0.002, -0.003])
+    pim_b = oracle.imu_preintegrate(samples_const(a + b[:3], b[3:], 40), b, ACC_COV, GYRO_COV, INT_COV)
+    assert np.allclose(pim_b[P["DV"]:P["DV"] + 3], a * 0.2, rtol=1e-12)
+    assert np.allclose(pim_b[P["DR"]:P["DR"] + 9].reshape(3, 3), np.eye(3), atol=1e-14)
+    # covariance: symmetric positive definite, grows with the interval
+    C = pim[P["COV"]:P["COV"] + 81].reshape(9, 9)
+    assert np.allclose(C, C.T, atol=1e-20) and np.linalg.eigvalsh(C).min() > 0
+    C2 = oracle.imu_preintegrate(samples_const(a, np.zeros(3), 80), np.zeros(6), ACC_COV, GYRO_COV, INT_COV)[P["COV"]:P["COV"] + 81].reshape(9, 9)
+    assert np.trace(C2) > np.trace(C)
+    # gyro block of a pure-noise integration = sum Jr dt (gyro_cov/dt) Jr^T dt = gyro_cov * T for omega = 0
+    assert np.allclose(C[:3, :3], GYRO_COV * 0.2, rtol=1e-12)
+    W = oracle.sqrt_information(C)
+    assert np.allclose(W.T @ W, np.linalg.inv(C), rtol=1e-8)
+
+
+def test_bias_jacobians_of_the_preintegration_match_finite_differences(oracle):
+    P = oracle.PIM
+    rng = np.random.default_rng(0)
+    S = np.concatenate([rng.normal(size=(30, 3)) * 2 + [0, 0, 9.8], rng.normal(size=(30, 3)) * 0.5, np.full((30, 1), 0.005)], 1)
+    b0 = rng.normal(size=6) * 0.05
+    pim = oracle.imu_preintegrate(S, b0, ACC_COV, GYRO_COV, INT_COV)
+    h = 1e-6
+    for k in range(6):
+        e = np.zeros(6); e[k] = h
+        pp = oracle.imu_preintegrate(S, b0 + e, ACC_COV, GYRO_COV, INT_COV)
+        pm = oracle.imu_preintegrate(S, b0 - e, ACC_COV, GYRO_COV, INT_COV)
+        dP = (pp[P["DP"]:P["DP"] + 3] - pm[P["DP"]:P["DP"] + 3]) / (2 * h)
+        dV = (pp[P["DV"]:P["DV"] + 3] - pm[P["DV"]:P["DV"] + 3]) / (2 * h)
+        name = ("DBA", k) if k < 3 else ("DBG", k - 3)
+        assert np.allclose(dP, pim[P["DP_" + name[0]]:P["DP_" + name[0]] + 9].reshape(3, 3)[:, name[1]], rtol=1e-5, atol=1e-9)
+        assert np.allclose(dV, pim[P["DV_" + name[0]]:P["DV_" + name[0]] + 9].reshape(3, 3)[:, name[1]], rtol=1e-5, atol=1e-9)
+        if k >= 3:      # rotation: Log(dR^T dR(b+e)) / h
+            Rp = pp[P["DR"]:P["DR"] + 9].reshape(3, 3); Rm = pm[P["DR"]:P["DR"] + 9].reshape(3, 3)
+            from scipy.spatial.transform import Rotation
+            d = Rotation.from_matrix(Rm.T @ Rp).as_rotvec() / (2 * h)
+            assert np.allclose(d, pim[P["DR_DBG"]:P["DR_DBG"] + 9].reshape(3, 3)[:, k - 3], rtol=1e-5, atol=1e-8)
+
+
+def predict(oracle, Ti, vi, pim, dt):
+    P = oracle.PIM
+    Ri = Ti[:9].reshape(3, 3)
+    dR = pim[P["DR"]:P["DR"] + 9].reshape(3, 3)
+    Tj = np.concatenate([(Ri @ dR).reshape(-1), Ti[9:] + vi * dt + 0.5 * G * dt ** 2 + Ri @ pim[P["DP"]:P["DP"] + 3]])
+    vj = vi + G * dt + Ri @ pim[P["DV"]:P["DV"] + 3]
+    return Tj, vj
+
+
+def test_imu_factor_residual_is_zero_on_the_predicted_state_and_jacobians_match_fd(oracle):
+    rng = np.random.default_rng(1)
+    S = np.concatenate([rng.normal(size=(40, 3)) + [0, 0, 9.8], rng.normal(size=(40, 3)) * 0.3, np.full((40, 1), 0.005)], 1)
+    bhat = rng.normal(size=6) * 0.02
+    pim = oracle.imu_preintegrate(S, bhat, ACC_COV, GYRO_COV, INT_COV)
+    Ti, vi = rand_pose(rng), rng.normal(size=3)
+    Tj, vj = predict(oracle, Ti, vi, pim, 0.2)
+    r, J = oracle.imu_factor(Ti, vi, Tj, vj, bhat, pim, G)
+    assert np.abs(r).max() < 1e-12
+    # perturbed states and a bias away from the linearisation point
+    Tj2 = oracle.pose_retract(Tj, rng.normal(size=6) * 0.05)
+    vj2 = vj + rng.normal(size=3) * 0.1
+    bias = bhat + rng.normal(size=6) * 0.01
+    r, J = oracle.imu_factor(Ti, vi, Tj2, vj2, bias, pim, G)
+    assert np.abs(r).max() > 1e-3
+    h = 1e-6
+    Jn = np.zeros((9, 24))
+
+    def f(xi_i, dvi, xi_j, dvj, db):
+        return oracle.imu_factor(oracle.pose_retract(Ti, xi_i), vi + dvi, oracle.pose_retract(Tj2, xi_j), vj2 + dvj,
+                                 bias + db, pim, G, jac=False)
+    for k in range(24):
+        args_p = [np.zeros(6), np.zeros(3), np.zeros(6), np.zeros(3), np.zeros(6)]
+        args_m = [np.zeros(6), np.zeros(3), np.zeros(6), np.zeros(3), np.zeros(6)]
+        blk, off = [(0, 0), (1, 6), (2, 9), (3, 15), (4, 18)][sum(k >= o for o in (6, 9, 15, 18))]
+        args_p[blk][k - off] = h; args_m[blk][k - off] = -h
+        Jn[:, k] = (f(*args_p) - f(*args_m)) / (2 * h)
+    assert np.allclose(J, Jn, rtol=2e-5, atol=2e-6), np.abs(J - Jn).max()
+
+
+def test_dvl_factor_residual_and_jacobians(oracle):
+    rng = np.random.default_rng(2)
+    T, v, m = rand_pose(rng), rng.normal(size=3), rng.normal(size=3)
+    e, JX, Jv = oracle.dvl_factor(T, v, m)
+    assert np.allclose(e, T[:9].reshape(3, 3) @ m - v)               # batch.py:221-229
+    assert np.array_equal(Jv, -np.eye(3))
+    h = 1e-6
+    for k in range(6):
+        d = np.zeros(6); d[k] = h
+        ep, _, _ = oracle.dvl_factor(oracle.pose_retract(T, d), v, m)
+        em, _, _ = oracle.dvl_factor(oracle.pose_retract(T, -d), v, m)
+        assert np.allclose((ep - em) / (2 * h), JX[:, k], atol=1e-8)
+    assert not JX[:, 3:].any()        # the velocity residual does not depend on the position
