@@ -317,3 +317,57 @@ def so3_expmap(w):
     R = np.zeros(9)
     lib().vus_so3_expmap_cpu(_p(_f64(w)), _p(R))
     return R.reshape(3, 3)
+
+
+class _NavFactors(ctypes.Structure):
+    _fields_ = [("n_imu", c_int), ("imu_i", c_void_p), ("imu_j", c_void_p), ("imu_pim", c_void_p), ("imu_W", c_void_p),
+                ("gravity", c_double * 3), ("n_dvl", c_int), ("dvl_pose", c_void_p), ("dvl_meas", c_void_p),
+                ("dvl_w", c_void_p), ("n_vprior", c_int), ("vprior_idx", c_void_p), ("vprior_v", c_void_p),
+                ("vprior_w", c_void_p)]
+
+
+class NavFactors:
+    """Host-side vus_nav_factors: imu = (i [n], j [n], pim [n,148], W [n,81]), dvl = (pose [n], meas [n,3], sigma [n]),
+    vprior = (idx [n], v [n,3], sigmas [n,3])."""
+
+    def __init__(self, gravity, imu=None, dvl=None, vprior=None):
+        z = np.zeros(0)
+        self.imu_i = np.ascontiguousarray(imu[0] if imu else z, np.int32)
+        self.imu_j = np.ascontiguousarray(imu[1] if imu else z, np.int32)
+        self.imu_pim = _f64(imu[2] if imu else z)
+        self.imu_W = _f64(imu[3] if imu else z)
+        self.dvl_pose = np.ascontiguousarray(dvl[0] if dvl else z, np.int32)
+        self.dvl_meas = _f64(dvl[1] if dvl else z)
+        self.dvl_w = _f64(1.0 / np.asarray(dvl[2], float)) if dvl else z
+        self.vp_idx = np.ascontiguousarray(vprior[0] if vprior else z, np.int32)
+        self.vp_v = _f64(vprior[1] if vprior else z)
+        self.vp_w = _f64(1.0 / np.asarray(vprior[2], float)) if vprior else z
+        pv = lambda a: _p(a).value if a.size else None
+        self.c = _NavFactors(len(self.imu_i), pv(self.imu_i), pv(self.imu_j), pv(self.imu_pim), pv(self.imu_W),
+                             (c_double * 3)(*[float(x) for x in gravity]), len(self.dvl_pose), pv(self.dvl_pose),
+                             pv(self.dvl_meas), pv(self.dvl_w), len(self.vp_idx), pv(self.vp_idx), pv(self.vp_v), pv(self.vp_w))
+
+    def ref(self):
+        return ctypes.byref(self.c)
+
+
+def nav_error(P, N, poses, vels, bias, points):
+    e = np.zeros(1)
+    _check(lib().vus_nav_error_cpu(P.ref(), N.ref(), _p(_f64(poses)), _p(_f64(vels)), _p(_f64(bias)), _p(_f64(points)), _p(e)),
+           "nav_error")
+    return float(e[0])
+
+
+def nav_lm_optimize(P, N, poses, vels, bias, points, **params):
+    prm = dict(LM_DEFAULTS); prm.update(params)
+    c = _LMParams(*[prm[k] for k, _ in _LMParams._fields_])
+    rep = _LMReport()
+    cp = lambda a: np.array(a, dtype=np.float64, order="C", copy=True)
+    poses, vels, bias, points = cp(poses), cp(vels), cp(bias), cp(points)
+    _check(lib().vus_nav_lm_optimize_cpu(P.ref(), N.ref(), ctypes.byref(c), _p(poses), _p(vels), _p(bias), _p(points),
+                                         ctypes.byref(rep)), "nav_lm_optimize")
+    n = min(rep.outer, 128)
+    return poses, vels, bias, points, {"iterations": rep.iterations, "outer": rep.outer, "tries": rep.tries,
+                                       "status": rep.status, "initial_error": rep.initial_error,
+                                       "final_error": rep.final_error, "final_lambda": rep.final_lambda,
+                                       "err_hist": list(rep.err_hist[:n]), "lambda_hist": list(rep.lambda_hist[:n])}

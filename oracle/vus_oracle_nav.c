@@ -301,3 +301,303 @@ void vus_dvl_factor_cpu(const double* T, const double* v, const double* m, doubl
   }
   if (Jv) { memset(Jv, 0, sizeof(double) * 9); Jv[0] = Jv[4] = Jv[8] = -1.0; }
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * Full-graph Levenberg-Marquardt with navigation factors (oracle only: dense camera-side solve).
+ * Camera-side vector: for pose i [X_i (6), V_i (3)] at offset 9 i, then the shared bias (6).
+ * Same LM control flow as vus_ba_lm_optimize_cpu (gtsam defaults). */
+typedef struct vus_lm_params {
+  double lambda_initial, lambda_factor, lambda_upper, lambda_lower, min_model_fidelity;
+  double rel_tol, abs_tol, error_tol;
+  int max_iterations;
+} vus_lm_params;
+#define VUS_LM_HIST 128
+typedef struct vus_lm_report {
+  int iterations, outer, tries, status;
+  double initial_error, final_error, final_lambda;
+  double err_hist[VUS_LM_HIST];
+  double lambda_hist[VUS_LM_HIST];
+} vus_lm_report;
+
+int vus_ba_error_cpu(const vus_ba_problem* P, const double* poses, const double* points, double* err);
+int vus_ba_linearize_cpu(const vus_ba_problem* P, const double* poses, const double* points, double* W, double* V,
+                         double* gl, double* Hpp, double* gp, double* err);
+void vus_pose_retract_cpu(const double* T, const double* xi, double* out);
+void vus_stereo_factor_cpu(const double* T, const double* p, const double* m, const double* K, double w, double* r,
+                           double* H1, double* H2);
+
+/* error of the navigation factors; when H/g are given, also accumulate J^T J and J^T r (dense, ld = nc);
+ * when d (camera-side step) is given, return the LINEARISED error 0.5 |r + J d|^2 instead. */
+static double nav_terms(const vus_nav_factors* N, int nP, const double* poses, const double* vels, const double* bias,
+                        double* H, double* g, const double* d) {
+  const int nc = 9 * nP + 6;
+  double e = 0;
+  for (int f = 0; f < N->n_imu; ++f) {
+    const int i = N->imu_i[f], j = N->imu_j[f];
+    double r[9], J[9 * 24], rw[9], Jw[9 * 24];
+    vus_imu_factor_cpu(poses + 12 * i, vels + 3 * i, poses + 12 * j, vels + 3 * j, bias, N->imu_pim + PIM_DOUBLES * (size_t)f,
+                       N->gravity, r, (H || d) ? J : NULL);
+    const double* W = N->imu_W + 81 * (size_t)f;
+    for (int a = 0; a < 9; ++a) {
+      double t = 0;
+      for (int k = 0; k < 9; ++k) t += W[9 * a + k] * r[k];
+      rw[a] = t;
+    }
+    int col[24];
+    for (int k = 0; k < 9; ++k) { col[k] = 9 * i + k; col[9 + k] = 9 * j + k; }
+    for (int k = 0; k < 6; ++k) col[18 + k] = 9 * nP + k;
+    if (H || d) {
+      for (int a = 0; a < 9; ++a)
+        for (int c = 0; c < 24; ++c) {
+          double t = 0;
+          for (int k = 0; k < 9; ++k) t += W[9 * a + k] * J[24 * k + c];
+          Jw[24 * a + c] = t;
+        }
+    }
+    if (d)
+      for (int a = 0; a < 9; ++a)
+        for (int c = 0; c < 24; ++c) rw[a] += Jw[24 * a + c] * d[col[c]];
+    for (int a = 0; a < 9; ++a) e += 0.5 * rw[a] * rw[a];
+    if (H)
+      for (int c1 = 0; c1 < 24; ++c1) {
+        double t = 0;
+        for (int a = 0; a < 9; ++a) t += Jw[24 * a + c1] * rw[a];
+        g[col[c1]] += t;
+        for (int c2 = 0; c2 < 24; ++c2) {
+          double h = 0;
+          for (int a = 0; a < 9; ++a) h += Jw[24 * a + c1] * Jw[24 * a + c2];
+          H[(size_t)col[c1] * nc + col[c2]] += h;
+        }
+      }
+  }
+  for (int f = 0; f < N->n_dvl; ++f) {
+    const int i = N->dvl_pose[f];
+    const double w = N->dvl_w[f];
+    double r[3], JX[18], Jv[9];
+    vus_dvl_factor_cpu(poses + 12 * i, vels + 3 * i, N->dvl_meas + 3 * f, r, JX, Jv);
+    double Jw[3 * 9];
+    for (int a = 0; a < 3; ++a) {
+      r[a] *= w;
+      for (int c = 0; c < 6; ++c) Jw[9 * a + c] = w * JX[6 * a + c];
+      for (int c = 0; c < 3; ++c) Jw[9 * a + 6 + c] = w * Jv[3 * a + c];
+    }
+    if (d)
+      for (int a = 0; a < 3; ++a)
+        for (int c = 0; c < 9; ++c) r[a] += Jw[9 * a + c] * d[9 * i + c];
+    for (int a = 0; a < 3; ++a) e += 0.5 * r[a] * r[a];
+    if (H)
+      for (int c1 = 0; c1 < 9; ++c1) {
+        double t = 0;
+        for (int a = 0; a < 3; ++a) t += Jw[9 * a + c1] * r[a];
+        g[9 * i + c1] += t;
+        for (int c2 = 0; c2 < 9; ++c2) {
+          double h = 0;
+          for (int a = 0; a < 3; ++a) h += Jw[9 * a + c1] * Jw[9 * a + c2];
+          H[(size_t)(9 * i + c1) * nc + 9 * i + c2] += h;
+        }
+      }
+  }
+  for (int f = 0; f < N->n_vprior; ++f) {
+    const int i = N->vprior_idx[f];
+    for (int k = 0; k < 3; ++k) {
+      const double w = N->vprior_w[3 * f + k];
+      double r = w * (vels[3 * i + k] - N->vprior_v[3 * f + k]);
+      if (d) r += w * d[9 * i + 6 + k];
+      e += 0.5 * r * r;
+      if (H) { g[9 * i + 6 + k] += w * r; H[(size_t)(9 * i + 6 + k) * nc + 9 * i + 6 + k] += w * w; }
+    }
+  }
+  return e;
+}
+
+static int dense_cholesky_solve(double* A, int n, double* b) { /* A overwritten; returns 0 ok */
+  for (int c = 0; c < n; ++c) {
+    double s = A[(size_t)c * n + c];
+    for (int k = 0; k < c; ++k) s -= A[(size_t)c * n + k] * A[(size_t)c * n + k];
+    if (!(s > 0.0)) return c + 1;
+    double l = sqrt(s);
+    A[(size_t)c * n + c] = l;
+    for (int r = c + 1; r < n; ++r) {
+      double t = A[(size_t)r * n + c];
+      for (int k = 0; k < c; ++k) t -= A[(size_t)r * n + k] * A[(size_t)c * n + k];
+      A[(size_t)r * n + c] = t / l;
+    }
+  }
+  for (int r = 0; r < n; ++r) { double t = b[r]; for (int k = 0; k < r; ++k) t -= A[(size_t)r * n + k] * b[k]; b[r] = t / A[(size_t)r * n + r]; }
+  for (int c = n - 1; c >= 0; --c) { double t = b[c]; for (int r = c + 1; r < n; ++r) t -= A[(size_t)r * n + c] * b[r]; b[c] = t / A[(size_t)c * n + c]; }
+  return 0;
+}
+
+static void sym3_inv(const double* v, double* o) {
+  double a = v[0], b = v[1], c = v[2], d = v[3], e = v[4], f = v[5];
+  double c00 = d * f - e * e, c01 = c * e - b * f, c02 = b * e - c * d;
+  double id = 1.0 / (a * c00 + b * c01 + c * c02);
+  o[0] = c00 * id; o[1] = c01 * id; o[2] = c02 * id; o[3] = (a * f - c * c) * id; o[4] = (b * c - a * e) * id; o[5] = (a * d - b * b) * id;
+}
+static inline double s3(const double* v, int r, int c) { static const int ix[3][3] = {{0, 1, 2}, {1, 3, 4}, {2, 4, 5}}; return v[ix[r][c]]; }
+
+static double nav_total_error(const vus_ba_problem* P, const vus_nav_factors* N, const double* poses, const double* vels,
+                              const double* bias, const double* points) {
+  double e;
+  vus_ba_error_cpu(P, poses, points, &e);
+  return e + nav_terms(N, P->n_poses, poses, vels, bias, NULL, NULL, NULL);
+}
+
+int vus_nav_error_cpu(const vus_ba_problem* P, const vus_nav_factors* N, const double* poses, const double* vels,
+                      const double* bias, const double* points, double* err) {
+  if (!P || !N || !poses || !vels || !bias || !points || !err) return VUS_E_INVALID;
+  err[0] = nav_total_error(P, N, poses, vels, bias, points);
+  return VUS_OK;
+}
+
+int vus_nav_lm_optimize_cpu(const vus_ba_problem* P, const vus_nav_factors* N, const vus_lm_params* prm, double* poses,
+                            double* vels, double* bias, double* points, vus_lm_report* rep) {
+  if (!P || !N || !prm || !poses || !vels || !bias || !points || !rep) return VUS_E_INVALID;
+  const int nP = P->n_poses, nL = P->n_points, nO = P->n_obs, nc = 9 * nP + 6;
+  double* W = malloc(sizeof(double) * 18 * (size_t)(nO + 1));
+  double* Y = malloc(sizeof(double) * 18 * (size_t)(nO + 1));
+  double* V = malloc(sizeof(double) * 6 * (size_t)(nL + 1));
+  double* Vinv = malloc(sizeof(double) * 6 * (size_t)(nL + 1));
+  double* gl = malloc(sizeof(double) * 3 * (size_t)(nL + 1));
+  double* dl = malloc(sizeof(double) * 3 * (size_t)(nL + 1));
+  double* Hpp = malloc(sizeof(double) * 36 * (size_t)nP);
+  double* gp = malloc(sizeof(double) * 6 * (size_t)nP);
+  double* H = malloc(sizeof(double) * (size_t)nc * nc);
+  double* S = malloc(sizeof(double) * (size_t)nc * nc);
+  double* g = malloc(sizeof(double) * nc);
+  double* d = malloc(sizeof(double) * nc);
+  double* nposes = malloc(sizeof(double) * 12 * (size_t)nP);
+  double* nvels = malloc(sizeof(double) * 3 * (size_t)nP);
+  double* npoints = malloc(sizeof(double) * 3 * (size_t)(nL + 1));
+  double nbias[6];
+  memset(rep, 0, sizeof *rep);
+  double lambda = prm->lambda_initial;
+  double current = nav_total_error(P, N, poses, vels, bias, points);
+  rep->initial_error = current;
+  rep->status = 1;
+  while (rep->iterations < prm->max_iterations) {
+    double lin_stereo;
+    vus_ba_linearize_cpu(P, poses, points, W, V, gl, Hpp, gp, &lin_stereo);
+    memset(H, 0, sizeof(double) * (size_t)nc * nc);
+    memset(g, 0, sizeof(double) * nc);
+    for (int i = 0; i < nP; ++i)
+      for (int r = 0; r < 6; ++r) {
+        g[9 * i + r] = gp[6 * i + r];
+        for (int c = 0; c < 6; ++c) H[(size_t)(9 * i + r) * nc + 9 * i + c] = Hpp[36 * i + 6 * r + c];
+      }
+    const double lin0 = lin_stereo + nav_terms(N, nP, poses, vels, bias, H, g, NULL);
+    double new_error = current;
+    int stop_search = 0, accepted = 0;
+    for (;;) {
+      memcpy(S, H, sizeof(double) * (size_t)nc * nc);
+      memcpy(d, g, sizeof(double) * nc);
+      for (int k = 0; k < nc; ++k) S[(size_t)k * nc + k] += lambda;
+      for (int j = 0; j < nL; ++j) {
+        double Vd[6];
+        for (int k = 0; k < 6; ++k) Vd[k] = V[6 * j + k];
+        Vd[0] += lambda; Vd[3] += lambda; Vd[5] += lambda;
+        sym3_inv(Vd, Vinv + 6 * j);
+        const double* Vi = Vinv + 6 * j;
+        for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a) {
+          const double* Wa = W + 18 * (size_t)P->obs_ppos[a];
+          double* Ya = Y + 18 * (size_t)P->obs_ppos[a];
+          for (int rr = 0; rr < 6; ++rr)
+            for (int c = 0; c < 3; ++c)
+              Ya[3 * rr + c] = Wa[3 * rr] * s3(Vi, 0, c) + Wa[3 * rr + 1] * s3(Vi, 1, c) + Wa[3 * rr + 2] * s3(Vi, 2, c);
+          const int ia = P->obs_pose[a];
+          for (int rr = 0; rr < 6; ++rr)
+            d[9 * ia + rr] -= Ya[3 * rr] * gl[3 * j] + Ya[3 * rr + 1] * gl[3 * j + 1] + Ya[3 * rr + 2] * gl[3 * j + 2];
+        }
+        for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a)
+          for (int b = P->point_ptr[j]; b < P->point_ptr[j + 1]; ++b) {
+            const int ia = P->obs_pose[a], ib = P->obs_pose[b];
+            const double* Ya = Y + 18 * (size_t)P->obs_ppos[a];
+            const double* Wb = W + 18 * (size_t)P->obs_ppos[b];
+            for (int rr = 0; rr < 6; ++rr)
+              for (int c = 0; c < 6; ++c)
+                S[(size_t)(9 * ia + rr) * nc + 9 * ib + c] -= Ya[3 * rr] * Wb[3 * c] + Ya[3 * rr + 1] * Wb[3 * c + 1] + Ya[3 * rr + 2] * Wb[3 * c + 2];
+          }
+      }
+      for (int k = 0; k < nc; ++k) d[k] = -d[k];
+      const int status = dense_cholesky_solve(S, nc, d);
+      ++rep->tries;
+      int success = 0;
+      if (status == 0) {
+        for (int j = 0; j < nL; ++j) {
+          double t[3] = {gl[3 * j], gl[3 * j + 1], gl[3 * j + 2]};
+          for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a) {
+            const double* Wa = W + 18 * (size_t)P->obs_ppos[a];
+            const double* dd = d + 9 * P->obs_pose[a];
+            for (int c = 0; c < 3; ++c)
+              for (int rr = 0; rr < 6; ++rr) t[c] += Wa[3 * rr + c] * dd[rr];
+          }
+          const double* Vi = Vinv + 6 * j;
+          for (int c = 0; c < 3; ++c) dl[3 * j + c] = -(s3(Vi, c, 0) * t[0] + s3(Vi, c, 1) * t[1] + s3(Vi, c, 2) * t[2]);
+        }
+        /* linearised error at the step */
+        double lin = nav_terms(N, nP, poses, vels, bias, NULL, NULL, d);
+        for (int a = 0; a < nO; ++a) {
+          const int i = P->obs_pose[a], j = P->obs_point[a];
+          double r[3], H1[18], H2[9];
+          vus_stereo_factor_cpu(poses + 12 * i, points + 3 * j, P->meas + 3 * a, P->K, P->inv_sigma, r, H1, H2);
+          for (int rr = 0; rr < 3; ++rr) {
+            double t = r[rr];
+            for (int c = 0; c < 6; ++c) t += H1[6 * rr + c] * d[9 * i + c];
+            for (int c = 0; c < 3; ++c) t += H2[3 * rr + c] * dl[3 * j + c];
+            lin += 0.5 * t * t;
+          }
+        }
+        for (int q = 0; q < P->n_priors; ++q) { /* pose priors: r + w d, with r from the linearisation */
+          const int i = P->prior_pose[q];
+          double xi[6];
+          extern void vus_pose_local_cpu(const double*, const double*, double*);
+          vus_pose_local_cpu(poses + 12 * i, P->prior_T + 12 * q, xi);
+          for (int k = 0; k < 6; ++k) {
+            const double w = P->prior_w[6 * q + k];
+            const double t = -xi[k] * w + w * d[9 * i + k];
+            lin += 0.5 * t * t;
+          }
+        }
+        for (int i = 0; i < nP; ++i) {
+          vus_pose_retract_cpu(poses + 12 * i, d + 9 * i, nposes + 12 * i);
+          for (int k = 0; k < 3; ++k) nvels[3 * i + k] = vels[3 * i + k] + d[9 * i + 6 + k];
+        }
+        for (int k = 0; k < 6; ++k) nbias[k] = bias[k] + d[9 * nP + k];
+        for (int k = 0; k < 3 * nL; ++k) npoints[k] = points[k] + dl[k];
+        const double nerr = nav_total_error(P, N, nposes, nvels, nbias, npoints);
+        const double lin_change = lin0 - lin;
+        if (lin_change >= 0.0) {
+          const double cost_change = current - nerr;
+          if (lin_change > 2.220446049250313e-16 * lin0) success = cost_change / lin_change > prm->min_model_fidelity;
+          if (fabs(cost_change) < prm->rel_tol * current) stop_search = 1;
+          if (success) {
+            memcpy(poses, nposes, sizeof(double) * 12 * (size_t)nP);
+            memcpy(vels, nvels, sizeof(double) * 3 * (size_t)nP);
+            memcpy(bias, nbias, sizeof nbias);
+            memcpy(points, npoints, sizeof(double) * 3 * (size_t)nL);
+            new_error = nerr;
+          }
+        }
+      }
+      if (success) { lambda /= prm->lambda_factor; if (lambda < prm->lambda_lower) lambda = prm->lambda_lower; accepted = 1; break; }
+      if (stop_search) break;
+      lambda *= prm->lambda_factor;
+      if (lambda >= prm->lambda_upper) { rep->status = 2; break; }
+    }
+    if (rep->outer < VUS_LM_HIST) { rep->err_hist[rep->outer] = new_error; rep->lambda_hist[rep->outer] = lambda; }
+    ++rep->outer;
+    rep->iterations += accepted;
+    int converged;
+    if (new_error <= prm->error_tol) converged = 1;
+    else { const double ad = current - new_error; converged = (ad / current <= prm->rel_tol) || (ad <= prm->abs_tol); }
+    current = new_error;
+    if (rep->status == 2) break;
+    if (converged) { rep->status = 0; break; }
+    if (!isfinite(current)) break;
+  }
+  rep->final_error = current;
+  rep->final_lambda = lambda;
+  free(W); free(Y); free(V); free(Vinv); free(gl); free(dl); free(Hpp); free(gp); free(H); free(S); free(g); free(d);
+  free(nposes); free(nvels); free(npoints);
+  return VUS_OK;
+}

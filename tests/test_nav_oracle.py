@@ -124,3 +124,64 @@ def test_dvl_factor_residual_and_jacobians(oracle):
         em, _, _ = oracle.dvl_factor(oracle.pose_retract(T, -d), v, m)
         assert np.allclose((ep - em) / (2 * h), JX[:, k], atol=1e-8)
     assert not JX[:, 3:].any()        # the velocity residual does not depend on the position
+
+
+def build_nav(oracle, s, with_dvl=True, zero_velocity_prior=True):
+    """Oracle-side problem of a synth.nav_sequence(): stereo + pose prior + IMU + DVL + velocity prior."""
+    import torch
+    from visual_underwater_slam_amd import ba_pack
+    from visual_underwater_slam_amd.gtsam.imu import Preintegrator
+    n_kf, nL = len(s["poses_gt"]), len(s["points_gt"])
+    pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"]), torch.from_numpy(s["obs_point"]),
+                                   torch.from_numpy(s["meas"]), n_kf, nL)
+    P = oracle.BAProblem(pk, s["K"], s["sigma"], (np.array([0], np.int32), s["poses_gt"][:1], s["prior_sigmas"][None]))
+    pims, Ws = [], []
+    for i in range(1, n_kf):
+        pre = Preintegrator(np.zeros(6), ACC_COV, GYRO_COV, INT_COV)
+        for smp in s["imu"][i - 1]:
+            pre.integrate(smp[:3], smp[3:6], smp[6])
+        pims.append(pre.packed()); Ws.append(pre.whitening().reshape(-1))
+    imu = (np.arange(0, n_kf - 1), np.arange(1, n_kf), np.array(pims), np.array(Ws))
+    dvl = (np.arange(1, n_kf), s["dvl"][1:], np.full(n_kf - 1, 0.1)) if with_dvl else None     # batch.py:98,292
+    # batch.py:282 puts a ZERO-velocity prior on V(0) even though the vehicle moves; the recovery test uses the truth
+    vprior = (np.array([0]), s["vels_gt"][:1] * (0.0 if zero_velocity_prior else 1.0), np.full((1, 3), 0.1))
+    N = oracle.NavFactors(s["gravity"], imu=imu, dvl=dvl, vprior=vprior)
+    return P, N
+
+
+def test_numpy_preintegration_equals_the_oracle(oracle):
+    from visual_underwater_slam_amd.gtsam.imu import Preintegrator
+    from visual_underwater_slam_amd import synth
+    s = synth.nav_sequence(4, 50, 20)
+    b = np.array([0.01, -0.02, 0.015, 0.002, -0.001, 0.003])
+    pre = Preintegrator(b, ACC_COV, GYRO_COV, INT_COV)
+    for smp in s["imu"][1]:
+        pre.integrate(smp[:3], smp[3:6], smp[6])
+    ref = oracle.imu_preintegrate(s["imu"][1], b, ACC_COV, GYRO_COV, INT_COV)
+    assert np.allclose(pre.packed(), ref, rtol=1e-12, atol=1e-18)
+    assert np.allclose(pre.whitening(), oracle.sqrt_information(pre.cov), rtol=1e-9)
+
+
+def test_nav_sequence_is_consistent_with_its_imu_and_dvl(oracle):
+    from visual_underwater_slam_amd import synth
+    s = synth.nav_sequence(8, 200, 60, meas_sigma=0.0)
+    P, N = build_nav(oracle, s)
+    # at the ground truth every inertial / DVL residual vanishes; only the velocity prior (prior 0 on a
+    # moving vehicle, as in batch.py:282) contributes
+    e = oracle.nav_error(P, N, s["poses_gt"], s["vels_gt"], np.zeros(6), s["points_gt"])
+    assert np.isclose(e, 0.5 * np.sum((s["vels_gt"][0] / 0.1) ** 2), rtol=1e-6)
+
+
+def test_full_graph_lm_recovers_ground_truth(oracle):
+    from visual_underwater_slam_amd import synth
+    s = synth.nav_sequence(12, 300, 60)
+    P, N = build_nav(oracle, s, zero_velocity_prior=False)
+    poses, vels, bias, points, rep = oracle.nav_lm_optimize(P, N, s["poses_init"], np.zeros_like(s["vels_gt"]), np.zeros(6),
+                                                            s["points_init"])
+    assert rep["status"] == 0 and rep["iterations"] >= 2
+    hist = [rep["initial_error"]] + rep["err_hist"]
+    assert all(b <= a * (1 + 1e-12) for a, b in zip(hist, hist[1:]))
+    assert rep["final_error"] < 1e-3 * rep["initial_error"]
+    assert np.abs(poses[:, 9:] - s["poses_gt"][:, 9:]).max() < 0.02
+    assert np.abs(vels[1:] - s["vels_gt"][1:]).max() < 0.05            # velocities start at 0 (batch.py:279)
+    assert np.abs(bias).max() < 0.05

@@ -202,3 +202,110 @@ def ba_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, line_len=None, kf_step=0.25, 
         "K": np.array([fx, fy, 0.0, cx, cy, BASELINE_M]), "sigma": STEREO_SIGMA,
         "prior_sigmas": np.array(PRIOR_SIGMAS), "line_len": line_len,
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# Stereo + IMU + DVL sequence (BASELINE.json configs[0]; IMU constants of /root/reference/batch.py:88,183-185,290)
+IMU_DT = 0.005
+GRAVITY = 9.81
+IMU_ACC_COV, IMU_GYRO_COV, IMU_INT_COV = 8.999999999999999e-08, 1.2184696791468346e-07, 1e-07
+
+
+def nav_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, kf_period=0.2, pose_sigma_t=0.05, pose_sigma_r=0.01,
+                 meas_sigma=1.0, dvl_sigma=0.0):
+    """Down-looking stereo rig on a smooth meandering track with a 200 Hz IMU (dt = 0.005, batch.py:290)
+    and a DVL (body-frame velocity).  The keyframe states are produced by integrating the sampled IMU
+    signals with the same discrete model the preintegration uses, so the inertial factors are exactly
+    consistent with the ground truth; the images see landmarks 2-6 m below the vehicle.
+
+    Returns the ba_sequence() dict plus: vels_gt [n_kf,3], imu [n_kf-1, n_per, 7] (ax,ay,az,wx,wy,wz,dt),
+    dvl [n_kf,3], gravity [3]."""
+    from .gtsam.imu import so3_expmap
+    n_per = int(round(kf_period / IMU_DT))
+    g = np.array([0.0, 0.0, -GRAVITY])
+    # desired smooth motion (analytic), camera/body z axis pointing down
+    R0 = np.diag([1.0, -1.0, -1.0])
+
+    def desired(t):
+        yaw = 0.35 * np.sin(0.15 * t)
+        pitch, roll = 0.04 * np.sin(0.5 * t), 0.03 * np.sin(0.37 * t + 1.0)
+        cy, sy, cp, sp, cr, sr = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+        Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+        Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+        p = np.array([1.25 * t, 1.5 * np.sin(0.2 * t), 0.15 * np.sin(0.3 * t)])
+        return Rz @ Ry @ Rx @ R0, p
+
+    def derivs(t, h=1e-4):
+        Rm, pm = desired(t - h); Rp, pp = desired(t + h); Rc, pc = desired(t)
+        vel = (pp - pm) / (2 * h)
+        acc = (pp - 2 * pc + pm) / (h * h)
+        dR = Rc.T @ (Rp - Rm) / (2 * h)
+        om = np.array([dR[2, 1] - dR[1, 2], dR[0, 2] - dR[2, 0], dR[1, 0] - dR[0, 1]]) * 0.5
+        return Rc, pc, vel, om, Rc.T @ (acc - g)
+
+    Rk, pk, vk, _, _ = derivs(0.0)
+    poses = np.zeros((n_kf, 12)); vels = np.zeros((n_kf, 3))
+    imu = np.zeros((max(n_kf - 1, 0), n_per, 7))
+    poses[0, :9], poses[0, 9:], vels[0] = Rk.reshape(-1), pk, vk
+    for i in range(1, n_kf):
+        for s in range(n_per):
+            t = ((i - 1) * n_per + s + 0.5) * IMU_DT          # mid-interval sample of the smooth signals
+            _, _, _, om, ab = derivs(t)
+            imu[i - 1, s] = [*ab, *om, IMU_DT]
+            pk = pk + vk * IMU_DT + 0.5 * g * IMU_DT ** 2 + 0.5 * (Rk @ ab) * IMU_DT ** 2
+            vk = vk + g * IMU_DT + (Rk @ ab) * IMU_DT
+            Rk = Rk @ so3_expmap(om * IMU_DT)
+        poses[i, :9], poses[i, 9:], vels[i] = Rk.reshape(-1), pk, vk
+    # landmarks below the track
+    fx, fy, cx, cy = INTRINSIC
+    j = np.arange(n_lm, dtype=np.int64)
+    x_max = poses[-1, 9] + 3.0
+    pts = np.stack([-3.0 + (x_max + 3.0) * _hash_uniform(j, seed ^ 0x1111),
+                    -4.5 + 9.0 * _hash_uniform(j, seed ^ 0x2222),
+                    -(2.0 + 4.0 * _hash_uniform(j, seed ^ 0x3333))], 1)
+    obs_p, obs_l, meas = [], [], []
+    for i in range(n_kf):
+        R = poses[i, :9].reshape(3, 3)
+        q = (pts - poses[i, 9:]) @ R
+        z = q[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            uL = cx + fx * q[:, 0] / z
+            uR = cx + fx * (q[:, 0] - BASELINE_M) / z
+            v = cy + fy * q[:, 1] / z
+        vis = (z > 0.5) & (uL >= 0) & (uL < RES_X) & (uR >= 0) & (uR < RES_X) & (v >= 0) & (v < RES_Y)
+        idx = np.nonzero(vis)[0]
+        if len(idx) > obs_per_kf:
+            d2 = (uL[idx] - cx) ** 2 + (v[idx] - cy) ** 2
+            idx = np.sort(idx[np.argsort(d2, kind="stable")[:obs_per_kf]])
+        obs_p.append(np.full(len(idx), i, np.int32)); obs_l.append(idx.astype(np.int32))
+        meas.append(np.stack([uL[idx], uR[idx], v[idx]], 1))
+    obs_p, obs_l, meas = np.concatenate(obs_p), np.concatenate(obs_l), np.concatenate(meas)
+    used = np.unique(obs_l)
+    remap = -np.ones(n_lm, np.int64); remap[used] = np.arange(len(used))
+    obs_l = remap[obs_l].astype(np.int32); pts = pts[used]
+    order = np.lexsort((obs_p, obs_l))
+    obs_p, obs_l, meas = obs_p[order], obs_l[order], meas[order]
+    n_obs = len(obs_p)
+    meas = meas + meas_sigma * _hash_normal(3 * n_obs, seed ^ 0x4444).reshape(n_obs, 3)
+    poses_init = poses.copy()
+    nt = pose_sigma_t * _hash_normal(3 * n_kf, seed ^ 0x5555).reshape(n_kf, 3)
+    nr = pose_sigma_r * _hash_normal(3 * n_kf, seed ^ 0x6666).reshape(n_kf, 3)
+    for i in range(1, n_kf):
+        poses_init[i, :9] = (poses[i, :9].reshape(3, 3) @ _rodrigues(nr[i])).reshape(-1)
+        poses_init[i, 9:] = poses[i, 9:] + nt[i]
+    first = np.concatenate([[0], np.nonzero(np.diff(obs_l))[0] + 1])
+    m0, p0 = meas[first], obs_p[first]
+    disp = np.maximum(m0[:, 0] - m0[:, 1], 0.5)
+    zc = fx * BASELINE_M / disp
+    cam = np.stack([(m0[:, 0] - cx) * zc / fx, (m0[:, 2] - cy) * zc / fy, zc], 1)
+    pts_init = np.einsum("nij,nj->ni", poses_init[p0, :9].reshape(-1, 3, 3), cam) + poses_init[p0, 9:]
+    dvl = np.einsum("nji,nj->ni", poses[:, :9].reshape(-1, 3, 3), vels)       # R^T v
+    if dvl_sigma > 0:
+        dvl = dvl + dvl_sigma * _hash_normal(3 * n_kf, seed ^ 0x7777).reshape(n_kf, 3)
+    return {
+        "poses_gt": poses, "poses_init": poses_init, "points_gt": pts, "points_init": pts_init,
+        "vels_gt": vels, "imu": imu, "dvl": dvl, "gravity": g,
+        "obs_pose": obs_p.astype(np.int32), "obs_point": obs_l.astype(np.int32), "meas": meas,
+        "K": np.array([fx, fy, 0.0, cx, cy, BASELINE_M]), "sigma": STEREO_SIGMA, "prior_sigmas": np.array(PRIOR_SIGMAS),
+    }
