@@ -140,6 +140,9 @@ typedef struct vus_ba_problem {
   const int* prior_pose;   /* [n_priors] pose index of each PriorFactorPose3 */
   const double* prior_T;   /* [n_priors,12] prior mean */
   const double* prior_w;   /* [n_priors,6] 1/sigma per tangent coordinate (rot xyz, trans xyz) */
+  int pose_stride;         /* camera-side node layout: pose i is node pose_stride*i (0 or 1: poses only;
+                              2: node 2i = X(i), node 2i+1 = V(i) padded to 6, for graphs with vus_nav_factors).
+                              Everything indexed "by node" (Sband rows, gs, dp) uses 6 doubles per node. */
 } vus_ba_problem;
 
 /* Camera-side "navigation" factors of the reference graph: velocity
@@ -209,10 +212,50 @@ int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lamb
  * value = -(n_ranks-1)*lambda restores a single copy. */
 int vus_ba_add_diag(double* Sband, int n_poses, int band, double value, void* stream);
 
-/* Solve S dp = -gs by block-band Cholesky (Sband is overwritten by its factor).
+/* Solve S dp = -gs by block-band Cholesky (Sband is overwritten by its factor); n_poses counts NODES.
  * status[0] = 0 ok, k+1 = non-positive pivot met in scalar column k (dp is then undefined). */
 int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, double* dp,
                       int* status, void* stream);
+
+/* Same factorisation with n_rhs (<= 8) right-hand sides solved in place: rhs [n_rhs, 6*n_nodes]
+ * (no sign change).  Used for the bias border of graphs with inertial factors. */
+int vus_ba_band_solve_multi(double* Sband, int n_nodes, int band, double* rhs, int n_rhs, int* status,
+                            void* stream);
+
+/* ---- navigation factors on the camera side (graphs with vus_nav_factors, pose_stride = 2) ----
+ * vus_nav_linearize: residuals/Jacobians of every ImuFactor / DVL factor / velocity prior at
+ * (poses, vels, bias), accumulated (in a fixed order) into
+ *   Snav [n_nodes,4,36]  blocks (node, node-s), s = 0..3   (undamped)
+ *   Scb  [n_nodes,36]    coupling of every node with the shared bias (node rows x bias columns)
+ *   Sbb  [36], gnav [6*n_nodes], gb [6]
+ *   err [1] = 0.5 * sum |whitened residual|^2 of these factors
+ * work: at least vus_nav_work_doubles(N) doubles. */
+int vus_nav_linearize(const vus_nav_factors* N, int n_poses, const double* poses, const double* vels,
+                      const double* bias, double* Snav, double* Scb, double* Sbb, double* gnav, double* gb,
+                      double* err, double* work, void* stream);
+long long vus_nav_work_doubles(const vus_nav_factors* N);
+
+/* Per lambda: Sband += Snav on the 4 innermost block diagonals, velocity nodes get lambda on their 3 real
+ * coordinates and 1 on the 3 padding coordinates, gs += gnav; rhs [7, 6*n_nodes] is filled with
+ * column 0 = -gs and columns 1..6 = the six columns of Scb. */
+int vus_nav_assemble(int n_nodes, int band, double lambda, const double* Snav, const double* Scb,
+                     const double* gnav, double* Sband, double* gs, double* rhs, void* stream);
+
+/* After vus_ba_band_solve_multi(rhs, 7): eliminate the bias border,
+ *   (Sbb + lambda I - Scb^T Z) db = -gb - Scb^T z0,   dc = z0 - Z db,
+ * dc [6*n_nodes] (node layout), db [6]. */
+int vus_nav_border_solve(int n_nodes, const double* rhs, const double* Scb, const double* Sbb, const double* gb,
+                         double lambda, double* dc, double* db, void* stream);
+
+/* new_vels = vels + dv (from dc), new_bias = bias + db;  out[0] = linearised error of the navigation factors
+ * at the step (Jacobians at the OLD values), out[1] = their error at the new values (new_poses from vus_ba_eval_step). */
+int vus_nav_eval_step(const vus_nav_factors* N, int n_poses, const double* poses, const double* vels,
+                      const double* bias, const double* dc, const double* db, const double* new_poses,
+                      double* new_vels, double* new_bias, double* out, double* work, void* stream);
+
+/* err[0] = error of the navigation factors at (poses, vels, bias). */
+int vus_nav_error(const vus_nav_factors* N, int n_poses, const double* poses, const double* vels,
+                  const double* bias, double* err, double* work, void* stream);
 
 /* dl [n_points,3] = -Vinv (gl + sum_a W_a^T dp[pose_a]). */
 int vus_ba_backsub(const vus_ba_problem* P, const double* W, const double* Vinv, const double* gl,

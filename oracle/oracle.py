@@ -141,7 +141,7 @@ class _BAProblem(ctypes.Structure):
                 ("K", c_void_p), ("inv_sigma", c_double), ("meas", c_void_p), ("obs_pose", c_void_p),
                 ("obs_point", c_void_p), ("point_ptr", c_void_p), ("obs_ppos", c_void_p),
                 ("pose_ptr", c_void_p), ("pobs_lidx", c_void_p), ("prior_pose", c_void_p),
-                ("prior_T", c_void_p), ("prior_w", c_void_p)]
+                ("prior_T", c_void_p), ("prior_w", c_void_p), ("pose_stride", c_int)]
 
 
 class _BAStructure(ctypes.Structure):
@@ -185,7 +185,7 @@ class BAProblem:
                             _p(self.arr["obs_ppos"]).value, _p(self.arr["pose_ptr"]).value,
                             _p(self.arr["pobs_lidx"]).value, _p(self.prior_pose).value if len(self.prior_pose) else None,
                             _p(self.prior_T).value if len(self.prior_pose) else None,
-                            _p(self.prior_w).value if len(self.prior_pose) else None)
+                            _p(self.prior_w).value if len(self.prior_pose) else None, 1)
 
     def ref(self):
         return ctypes.byref(self.c)
@@ -353,7 +353,7 @@ class NavFactors:
 
 def nav_error(P, N, poses, vels, bias, points):
     e = np.zeros(1)
-    _check(lib().vus_nav_error_cpu(P.ref(), N.ref(), _p(_f64(poses)), _p(_f64(vels)), _p(_f64(bias)), _p(_f64(points)), _p(e)),
+    _check(lib().vus_nav_total_error_cpu(P.ref(), N.ref(), _p(_f64(poses)), _p(_f64(vels)), _p(_f64(bias)), _p(_f64(points)), _p(e)),
            "nav_error")
     return float(e[0])
 

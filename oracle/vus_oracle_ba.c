@@ -327,17 +327,15 @@ static inline double* band_at(double* Sb, int B, int R, int C) {
   return Sb + 36 * ((size_t)i * (B + 1) + (i - k)) + 6 * (R % 6) + (C % 6);
 }
 
-int vus_ba_band_solve_cpu(double* Sband, int n_poses, int band, const double* gs, double* dp, int* status) {
-  if (!Sband || !gs || !dp || !status || n_poses < 1 || band < 0) return VUS_E_INVALID;
+/* left-looking Cholesky of the block band, lower factor in place; returns 0 or failing column + 1 */
+static int band_factor(double* Sband, int n_poses, int band) {
   const int n = 6 * n_poses, B = band;
-  status[0] = 0;
-  /* left-looking Cholesky, lower factor in place */
   for (int C = 0; C < n; ++C) {
     int kc0 = (C / 6 - B) * 6;
     if (kc0 < 0) kc0 = 0;
     double s = *band_at(Sband, B, C, C);
     for (int k = kc0; k < C; ++k) { double l = *band_at(Sband, B, C, k); s -= l * l; }
-    if (!(s > 0.0)) { status[0] = C + 1; return VUS_OK; }
+    if (!(s > 0.0)) return C + 1;
     double lcc = sqrt(s);
     *band_at(Sband, B, C, C) = lcc;
     int Rmax = (C / 6 + B) * 6 + 5;
@@ -350,22 +348,42 @@ int vus_ba_band_solve_cpu(double* Sband, int n_poses, int band, const double* gs
       *band_at(Sband, B, R, C) = t / lcc;
     }
   }
-  /* L y = -gs */
+  return 0;
+}
+
+/* x <- L^-T L^-1 x */
+static void band_substitute(double* Sband, int n_poses, int band, double* x) {
+  const int n = 6 * n_poses, B = band;
   for (int R = 0; R < n; ++R) {
     int k0 = (R / 6 - B) * 6;
     if (k0 < 0) k0 = 0;
-    double t = -gs[R];
-    for (int k = k0; k < R; ++k) t -= *band_at(Sband, B, R, k) * dp[k];
-    dp[R] = t / *band_at(Sband, B, R, R);
+    double t = x[R];
+    for (int k = k0; k < R; ++k) t -= *band_at(Sband, B, R, k) * x[k];
+    x[R] = t / *band_at(Sband, B, R, R);
   }
-  /* L^T x = y */
   for (int C = n - 1; C >= 0; --C) {
     int Rmax = (C / 6 + B) * 6 + 5;
     if (Rmax > n - 1) Rmax = n - 1;
-    double t = dp[C];
-    for (int R = C + 1; R <= Rmax; ++R) t -= *band_at(Sband, B, R, C) * dp[R];
-    dp[C] = t / *band_at(Sband, B, C, C);
+    double t = x[C];
+    for (int R = C + 1; R <= Rmax; ++R) t -= *band_at(Sband, B, R, C) * x[R];
+    x[C] = t / *band_at(Sband, B, C, C);
   }
+}
+
+int vus_ba_band_solve_cpu(double* Sband, int n_poses, int band, const double* gs, double* dp, int* status) {
+  if (!Sband || !gs || !dp || !status || n_poses < 1 || band < 0) return VUS_E_INVALID;
+  status[0] = band_factor(Sband, n_poses, band);
+  if (status[0]) return VUS_OK;
+  for (int k = 0; k < 6 * n_poses; ++k) dp[k] = -gs[k];
+  band_substitute(Sband, n_poses, band, dp);
+  return VUS_OK;
+}
+
+int vus_ba_band_solve_multi_cpu(double* Sband, int n_nodes, int band, double* rhs, int n_rhs, int* status) {
+  if (!Sband || !rhs || !status || n_nodes < 1 || band < 0 || n_rhs < 1 || n_rhs > 8) return VUS_E_INVALID;
+  status[0] = band_factor(Sband, n_nodes, band);
+  if (status[0]) return VUS_OK;
+  for (int q = 0; q < n_rhs; ++q) band_substitute(Sband, n_nodes, band, rhs + (size_t)q * 6 * n_nodes);
   return VUS_OK;
 }
 

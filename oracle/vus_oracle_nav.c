@@ -443,8 +443,8 @@ static double nav_total_error(const vus_ba_problem* P, const vus_nav_factors* N,
   return e + nav_terms(N, P->n_poses, poses, vels, bias, NULL, NULL, NULL);
 }
 
-int vus_nav_error_cpu(const vus_ba_problem* P, const vus_nav_factors* N, const double* poses, const double* vels,
-                      const double* bias, const double* points, double* err) {
+int vus_nav_total_error_cpu(const vus_ba_problem* P, const vus_nav_factors* N, const double* poses, const double* vels,
+                            const double* bias, const double* points, double* err) {
   if (!P || !N || !poses || !vels || !bias || !points || !err) return VUS_E_INVALID;
   err[0] = nav_total_error(P, N, poses, vels, bias, points);
   return VUS_OK;
@@ -599,5 +599,123 @@ int vus_nav_lm_optimize_cpu(const vus_ba_problem* P, const vus_nav_factors* N, c
   rep->final_lambda = lambda;
   free(W); free(Y); free(V); free(Vinv); free(gl); free(dl); free(Hpp); free(gp); free(H); free(S); free(g); free(d);
   free(nposes); free(nvels); free(npoints);
+  return VUS_OK;
+}
+
+
+/* ---------------------------------------------------------------------------------------------
+ * Twins of the navigation entry points of include/vus.h (node layout: node 2i = X(i), 2i+1 = V(i)
+ * padded to 6, bias as a border) -- used to check the HIP kernels stage by stage. */
+static void dense_to_nodes(int nP, const double* H, const double* g, double* Snav, double* Scb, double* Sbb,
+                           double* gnav, double* gb) {
+  const int nc = 9 * nP + 6, nn = 2 * nP;
+  memset(Snav, 0, sizeof(double) * 36 * 4 * (size_t)nn);
+  memset(Scb, 0, sizeof(double) * 36 * (size_t)nn);
+  memset(gnav, 0, sizeof(double) * 6 * (size_t)nn);
+  /* dense index -> (node, dim) */
+  for (int r = 0; r < 9 * nP; ++r) {
+    const int i = r / 9, k = r % 9, n1 = k < 6 ? 2 * i : 2 * i + 1, d1 = k < 6 ? k : k - 6;
+    gnav[6 * n1 + d1] = g[r];
+    for (int c = 0; c < 9 * nP; ++c) {
+      const int j = c / 9, kk = c % 9, n2 = kk < 6 ? 2 * j : 2 * j + 1, d2 = kk < 6 ? kk : kk - 6;
+      if (n1 >= n2 && n1 - n2 <= 3) Snav[36 * ((size_t)n1 * 4 + (n1 - n2)) + 6 * d1 + d2] = H[(size_t)r * nc + c];
+    }
+    for (int q = 0; q < 6; ++q) Scb[36 * (size_t)n1 + 6 * d1 + q] = H[(size_t)r * nc + 9 * nP + q];
+  }
+  for (int a = 0; a < 6; ++a) {
+    gb[a] = g[9 * nP + a];
+    for (int b = 0; b < 6; ++b) Sbb[6 * a + b] = H[(size_t)(9 * nP + a) * nc + 9 * nP + b];
+  }
+}
+
+int vus_nav_linearize_cpu(const vus_nav_factors* N, int n_poses, const double* poses, const double* vels,
+                          const double* bias, double* Snav, double* Scb, double* Sbb, double* gnav, double* gb,
+                          double* err, double* work) {
+  (void)work;
+  if (!N || !poses || !vels || !bias || !Snav || !Scb || !Sbb || !gnav || !gb || !err) return VUS_E_INVALID;
+  const int nc = 9 * n_poses + 6;
+  double* H = calloc((size_t)nc * nc, sizeof(double));
+  double* g = calloc(nc, sizeof(double));
+  err[0] = nav_terms(N, n_poses, poses, vels, bias, H, g, NULL);
+  dense_to_nodes(n_poses, H, g, Snav, Scb, Sbb, gnav, gb);
+  free(H); free(g);
+  return VUS_OK;
+}
+
+int vus_nav_assemble_cpu(int n_nodes, int band, double lambda, const double* Snav, const double* Scb,
+                         const double* gnav, double* Sband, double* gs, double* rhs) {
+  if (!Snav || !Scb || !gnav || !Sband || !gs || !rhs || n_nodes < 2 || band < 1) return VUS_E_INVALID;
+  const int smax = band < 3 ? band : 3;
+  for (int node = 0; node < n_nodes; ++node) {
+    for (int s = 0; s <= smax; ++s)
+      for (int e = 0; e < 36; ++e) {
+        double v = Snav[36 * ((size_t)node * 4 + s) + e];
+        if (s == 0 && (node & 1) && e % 7 == 0) v += (e / 7 < 3) ? lambda : 1.0;
+        Sband[36 * ((size_t)node * (band + 1) + s) + e] += v;
+      }
+    for (int d = 0; d < 6; ++d) {
+      const size_t k = 6 * (size_t)node + d;
+      gs[k] += gnav[k];
+      rhs[k] = -gs[k];
+      for (int q = 0; q < 6; ++q) rhs[(size_t)(1 + q) * 6 * n_nodes + k] = Scb[36 * (size_t)node + 6 * d + q];
+    }
+  }
+  return VUS_OK;
+}
+
+int vus_nav_border_solve_cpu(int n_nodes, const double* rhs, const double* Scb, const double* Sbb, const double* gb,
+                             double lambda, double* dc, double* db) {
+  if (!rhs || !Scb || !Sbb || !gb || !dc || !db || n_nodes < 1) return VUS_E_INVALID;
+  const size_t n = 6 * (size_t)n_nodes;
+  double M[36], v[6];
+  for (int a = 0; a < 6; ++a) {
+    v[a] = -gb[a];
+    for (int b = 0; b < 6; ++b) M[6 * a + b] = Sbb[6 * a + b] + (a == b ? lambda : 0.0);
+  }
+  for (size_t k = 0; k < n; ++k) {
+    const double* c = Scb + 36 * (k / 6) + 6 * (k % 6);
+    for (int a = 0; a < 6; ++a) {
+      v[a] -= c[a] * rhs[k];
+      for (int b = 0; b < 6; ++b) M[6 * a + b] -= c[a] * rhs[(size_t)(1 + b) * n + k];
+    }
+  }
+  if (dense_cholesky_solve(M, 6, v)) return VUS_E_INVALID;
+  for (int k = 0; k < 6; ++k) db[k] = v[k];
+  for (size_t k = 0; k < n; ++k) {
+    double t = rhs[k];
+    for (int b = 0; b < 6; ++b) t -= rhs[(size_t)(1 + b) * n + k] * v[b];
+    dc[k] = t;
+  }
+  return VUS_OK;
+}
+
+static void nodes_to_dense_step(int nP, const double* dc, const double* db, double* d) {
+  for (int i = 0; i < nP; ++i) {
+    for (int k = 0; k < 6; ++k) d[9 * i + k] = dc[6 * (2 * i) + k];
+    for (int k = 0; k < 3; ++k) d[9 * i + 6 + k] = dc[6 * (2 * i + 1) + k];
+  }
+  for (int k = 0; k < 6; ++k) d[9 * nP + k] = db[k];
+}
+
+int vus_nav_eval_step_cpu(const vus_nav_factors* N, int n_poses, const double* poses, const double* vels,
+                          const double* bias, const double* dc, const double* db, const double* new_poses,
+                          double* new_vels, double* new_bias, double* out, double* work) {
+  (void)work;
+  if (!N || !poses || !vels || !bias || !dc || !db || !new_poses || !new_vels || !new_bias || !out) return VUS_E_INVALID;
+  double* d = malloc(sizeof(double) * (9 * (size_t)n_poses + 6));
+  nodes_to_dense_step(n_poses, dc, db, d);
+  for (int t = 0; t < 3 * n_poses; ++t) new_vels[t] = vels[t] + dc[6 * (2 * (t / 3) + 1) + t % 3];
+  for (int k = 0; k < 6; ++k) new_bias[k] = bias[k] + db[k];
+  out[0] = nav_terms(N, n_poses, poses, vels, bias, NULL, NULL, d);
+  out[1] = nav_terms(N, n_poses, new_poses, new_vels, new_bias, NULL, NULL, NULL);
+  free(d);
+  return VUS_OK;
+}
+
+int vus_nav_error_cpu(const vus_nav_factors* N, int n_poses, const double* poses, const double* vels,
+                      const double* bias, double* err, double* work) {
+  (void)work;
+  if (!N || !poses || !vels || !bias || !err) return VUS_E_INVALID;
+  err[0] = nav_terms(N, n_poses, poses, vels, bias, NULL, NULL, NULL);
   return VUS_OK;
 }

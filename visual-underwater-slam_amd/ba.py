@@ -24,7 +24,7 @@ class _CProblem(ctypes.Structure):
                 ("K", c_void_p), ("inv_sigma", c_double), ("meas", c_void_p), ("obs_pose", c_void_p),
                 ("obs_point", c_void_p), ("point_ptr", c_void_p), ("obs_ppos", c_void_p),
                 ("pose_ptr", c_void_p), ("pobs_lidx", c_void_p), ("prior_pose", c_void_p),
-                ("prior_T", c_void_p), ("prior_w", c_void_p)]
+                ("prior_T", c_void_p), ("prior_w", c_void_p), ("pose_stride", c_int)]
 
 
 class _CStructure(ctypes.Structure):
@@ -73,7 +73,7 @@ class StereoBAProblem:
     """Packed, device-resident stereo BA problem (vus_ba_problem + vus_ba_structure)."""
 
     def __init__(self, obs_pose, obs_point, meas, n_poses, n_points, K, sigma, prior_pose=None,
-                 prior_T=None, prior_sigmas=None, device="cuda:0", band=None):
+                 prior_T=None, prior_sigmas=None, device="cuda:0", band=None, pose_stride=1):
         _lib.require_gpu()
         _lib.load()
         dev = torch.device(device)
@@ -87,6 +87,10 @@ class StereoBAProblem:
         self.pk, self.st = pk, st
         self.device = dev
         self.n_poses, self.n_points, self.n_obs = int(n_poses), int(n_points), pk["n_obs"]
+        self.pose_stride = int(pose_stride)
+        self.n_nodes = self.pose_stride * int(n_poses)
+        if self.pose_stride > 1:        # node layout with velocity nodes: pose blocks are 2 nodes apart,
+            st["band"] = max(self.pose_stride * st["band"], 3)     # inertial factors reach 3 nodes back
         if band is not None:            # landmark-sharded solve: every rank allocates the global band
             if band < st["band"]:
                 raise ValueError(f"band={band} is smaller than this problem's own band {st['band']}")
@@ -109,7 +113,7 @@ class StereoBAProblem:
                                    p(pk["meas"]), p(pk["obs_pose"]), p(pk["obs_point"]), p(pk["point_ptr"]),
                                    p(pk["obs_ppos"]), p(pk["pose_ptr"]), p(pk["pobs_lidx"]),
                                    p(self.prior_pose) if n_pr else None, p(self.prior_T) if n_pr else None,
-                                   p(self.prior_w) if n_pr else None)
+                                   p(self.prior_w) if n_pr else None, int(pose_stride))
         self.c_structure = _CStructure(st["band"], st["n_blocks"], st["n_pairs"], p(st["blk_ptr"]), p(st["blk_i"]),
                                        p(st["blk_k"]), p(st["pair_a"]), p(st["pair_b"]))
         torch.cuda.synchronize(dev)
@@ -122,6 +126,7 @@ class StereoBASolver:
     def __init__(self, problem: StereoBAProblem):
         self.P = problem
         dev, nP, nL, nO, B = problem.device, problem.n_poses, problem.n_points, problem.n_obs, problem.band
+        nN = problem.n_nodes                       # camera-side nodes (= poses unless velocity nodes are interleaved)
         f64 = dict(dtype=torch.float64, device=dev)
         self.W = torch.empty((nO, 18), **f64)
         self.Y = torch.empty((nO, 18), **f64)
@@ -131,9 +136,9 @@ class StereoBASolver:
         self.dl = torch.empty((nL, 3), **f64)
         self.Hpp = torch.empty((nP, 36), **f64)
         self.gp = torch.empty((nP, 6), **f64)
-        self.gs = torch.empty((nP, 6), **f64)
-        self.dp = torch.empty((nP, 6), **f64)
-        self.Sband = torch.empty((nP, B + 1, 36), **f64)
+        self.gs = torch.empty((nN, 6), **f64)
+        self.dp = torch.empty((nN, 6), **f64)
+        self.Sband = torch.empty((nN, B + 1, 36), **f64)
         self.new_poses = torch.empty((nP, 12), **f64)
         self.new_points = torch.empty((nL, 3), **f64)
         self.work = torch.empty((2 * (nL + 1) + 8,), **f64)
@@ -162,7 +167,7 @@ class StereoBASolver:
 
     def band_solve(self):
         p = _lib.ptr
-        _lib.call("vus_ba_band_solve", p(self.Sband), self.P.n_poses, self.P.band, p(self.gs), p(self.dp),
+        _lib.call("vus_ba_band_solve", p(self.Sband), self.P.n_nodes, self.P.band, p(self.gs), p(self.dp),
                   p(self.status), _lib.current_stream_ptr())
 
     def backsub(self):
@@ -259,3 +264,176 @@ class StereoBASolver:
         rep.seconds = time.perf_counter() - t0
         rep.final_error, rep.final_lambda = current, lam
         return poses, points, rep
+
+
+# ---------------------------------------------------------------------------------------------
+# graphs with inertial / velocity factors
+class _CNav(ctypes.Structure):
+    _fields_ = [("n_imu", c_int), ("imu_i", c_void_p), ("imu_j", c_void_p), ("imu_pim", c_void_p), ("imu_W", c_void_p),
+                ("gravity", c_double * 3), ("n_dvl", c_int), ("dvl_pose", c_void_p), ("dvl_meas", c_void_p),
+                ("dvl_w", c_void_p), ("n_vprior", c_int), ("vprior_idx", c_void_p), ("vprior_v", c_void_p),
+                ("vprior_w", c_void_p)]
+
+
+class NavFactors:
+    """Device-resident vus_nav_factors.  imu = (i, j, pim [n,148], W [n,81]); dvl = (pose, meas [n,3], sigma [n]);
+    vprior = (idx, v [n,3], sigmas [n,3]).  ImuFactors must join consecutive poses (j = i + 1)."""
+
+    def __init__(self, gravity, imu=None, dvl=None, vprior=None, device="cuda:0"):
+        dev = torch.device(device)
+
+        def t(x, dt, shape):
+            return torch.as_tensor(x).to(device=dev, dtype=dt).reshape(shape).contiguous()
+        z = []
+        self.imu_i = t(imu[0] if imu else z, torch.int32, (-1,))
+        self.imu_j = t(imu[1] if imu else z, torch.int32, (-1,))
+        self.imu_pim = t(imu[2] if imu else z, torch.float64, (-1, 148))
+        self.imu_W = t(imu[3] if imu else z, torch.float64, (-1, 81))
+        if self.imu_i.numel() and bool((self.imu_j - self.imu_i != 1).any()):
+            raise NotImplementedError("ImuFactor between non-consecutive poses is not supported (batch.py:238 joins i-1 and i)")
+        self.dvl_pose = t(dvl[0] if dvl else z, torch.int32, (-1,))
+        self.dvl_meas = t(dvl[1] if dvl else z, torch.float64, (-1, 3))
+        self.dvl_w = (1.0 / t(dvl[2], torch.float64, (-1,))).contiguous() if dvl else t(z, torch.float64, (-1,))
+        self.vp_idx = t(vprior[0] if vprior else z, torch.int32, (-1,))
+        self.vp_v = t(vprior[1] if vprior else z, torch.float64, (-1, 3))
+        self.vp_w = (1.0 / t(vprior[2], torch.float64, (-1, 3))).contiguous() if vprior else t(z, torch.float64, (-1, 3))
+        pp = lambda x: _lib.ptr(x) if x.numel() else None
+        self.c = _CNav(self.imu_i.numel(), pp(self.imu_i), pp(self.imu_j), pp(self.imu_pim), pp(self.imu_W),
+                       (c_double * 3)(*[float(g) for g in gravity]), self.dvl_pose.numel(), pp(self.dvl_pose),
+                       pp(self.dvl_meas), pp(self.dvl_w), self.vp_idx.numel(), pp(self.vp_idx), pp(self.vp_v), pp(self.vp_w))
+        self.n_factors = self.imu_i.numel() + self.dvl_pose.numel() + self.vp_idx.numel()
+
+    def addr(self):
+        return ctypes.addressof(self.c)
+
+
+class NavBASolver(StereoBASolver):
+    """LM over poses, velocities, one shared IMU bias and landmarks.  The problem must have been built with
+    pose_stride=2 (velocity nodes interleaved); the bias is a 6-wide border eliminated after a
+    7-right-hand-side band solve."""
+
+    def __init__(self, problem: StereoBAProblem, nav: NavFactors):
+        if problem.pose_stride != 2:
+            raise ValueError("NavBASolver needs a StereoBAProblem built with pose_stride=2")
+        super().__init__(problem)
+        self.N = nav
+        dev, nP, nN = problem.device, problem.n_poses, problem.n_nodes
+        f64 = dict(dtype=torch.float64, device=dev)
+        self.Snav = torch.empty((nN, 4, 36), **f64)
+        self.Scb = torch.empty((nN, 36), **f64)
+        self.Sbb = torch.empty((36,), **f64)
+        self.gnav = torch.empty((nN, 6), **f64)
+        self.gb = torch.empty((6,), **f64)
+        self.rhs = torch.empty((7, nN * 6), **f64)
+        self.db = torch.empty((6,), **f64)
+        self.new_vels = torch.empty((nP, 3), **f64)
+        self.new_bias = torch.empty((6,), **f64)
+        self.nav_scal = torch.zeros((4,), **f64)
+        self.nav_work = torch.empty((int(_lib.load().vus_nav_work_doubles(nav.addr())),), **f64)
+
+    def nav_error(self, poses, vels, bias) -> float:
+        p = _lib.ptr
+        _lib.call("vus_nav_error", self.N.addr(), self.P.n_poses, p(poses), p(vels), p(bias), p(self.nav_scal),
+                  p(self.nav_work), _lib.current_stream_ptr())
+        return float(self.nav_scal[0].item())
+
+    def nav_linearize(self, poses, vels, bias):
+        p = _lib.ptr
+        _lib.call("vus_nav_linearize", self.N.addr(), self.P.n_poses, p(poses), p(vels), p(bias), p(self.Snav),
+                  p(self.Scb), p(self.Sbb), p(self.gnav), p(self.gb), p(self.nav_scal), p(self.nav_work),
+                  _lib.current_stream_ptr())
+
+    def nav_assemble(self, lam):
+        p = _lib.ptr
+        _lib.call("vus_nav_assemble", self.P.n_nodes, self.P.band, float(lam), p(self.Snav), p(self.Scb), p(self.gnav),
+                  p(self.Sband), p(self.gs), p(self.rhs), _lib.current_stream_ptr())
+
+    def nav_solve(self, lam):
+        p = _lib.ptr
+        st = _lib.current_stream_ptr()
+        _lib.call("vus_ba_band_solve_multi", p(self.Sband), self.P.n_nodes, self.P.band, p(self.rhs), 7, p(self.status), st)
+        _lib.call("vus_nav_border_solve", self.P.n_nodes, p(self.rhs), p(self.Scb), p(self.Sbb), p(self.gb), float(lam),
+                  p(self.dp), p(self.db), st)
+
+    def nav_eval_step(self, poses, vels, bias):
+        p = _lib.ptr
+        _lib.call("vus_nav_eval_step", self.N.addr(), self.P.n_poses, p(poses), p(vels), p(bias), p(self.dp), p(self.db),
+                  p(self.new_poses), p(self.new_vels), p(self.new_bias), p(self.nav_scal[1:]), p(self.nav_work),
+                  _lib.current_stream_ptr())
+
+    def optimize(self, poses, vels, bias, points, params: Optional[LMParams] = None):
+        """Returns (poses, vels, bias, points, LMReport); inputs untouched."""
+        prm = params or LMParams()
+        if prm.diagonalDamping or not prm.useFixedLambdaFactor:
+            raise NotImplementedError("only the gtsam defaults diagonalDamping=False, useFixedLambdaFactor=True")
+        c = lambda x: x.to(torch.float64).contiguous().clone()
+        poses, vels, bias, points = c(poses), c(vels), c(bias), c(points)
+        rep = LMReport(setup_seconds=self.P.setup_seconds)
+        torch.cuda.synchronize(self.P.device)
+        t0 = time.perf_counter()
+        lam = prm.lambdaInitial
+        current = self.error(poses, points) + self.nav_error(poses, vels, bias)
+        rep.initial_error = current
+        if current <= prm.errorTol or prm.maxIterations <= 0:
+            rep.status, rep.final_error, rep.final_lambda = 0, current, lam
+            return poses, vels, bias, points, rep
+        while rep.iterations < prm.maxIterations:
+            self.linearize(poses, points)
+            self.nav_linearize(poses, vels, bias)
+            new_error, stop_search, accepted, lin0 = current, False, False, None
+            while True:
+                self.schur(lam)
+                self.nav_assemble(lam)
+                self.nav_solve(lam)
+                self.backsub()
+                self.eval_step(poses, points)
+                self.nav_eval_step(poses, vels, bias)
+                sc, nsc = self.scal.cpu(), self.nav_scal.cpu()
+                status = int(self.status.item())
+                rep.tries += 1
+                if lin0 is None:
+                    lin0 = float(sc[0]) + float(nsc[0])
+                success = False
+                lin1, new1 = float(sc[1]) + float(nsc[1]), float(sc[2]) + float(nsc[2])
+                if status == 0 and math.isfinite(lin1) and math.isfinite(new1):
+                    lin_change = lin0 - lin1
+                    if lin_change >= 0.0:
+                        cost_change = current - new1
+                        if lin_change > 2.220446049250313e-16 * lin0:
+                            success = cost_change / lin_change > prm.minModelFidelity
+                        if abs(cost_change) < prm.relativeErrorTol * current:
+                            stop_search = True
+                        if success:
+                            poses, self.new_poses = self.new_poses, poses
+                            points, self.new_points = self.new_points, points
+                            vels, self.new_vels = self.new_vels, vels
+                            bias, self.new_bias = self.new_bias, bias
+                            new_error = new1
+                if success:
+                    lam = max(prm.lambdaLowerBound, lam / prm.lambdaFactor)
+                    accepted = True
+                    break
+                if stop_search:
+                    break
+                lam *= prm.lambdaFactor
+                if lam >= prm.lambdaUpperBound:
+                    rep.status = 2
+                    break
+            rep.err_hist.append(new_error)
+            rep.lambda_hist.append(lam)
+            rep.outer += 1
+            rep.iterations += int(accepted)
+            if new_error <= prm.errorTol:
+                converged = True
+            else:
+                abs_dec = current - new_error
+                converged = (abs_dec / current <= prm.relativeErrorTol) or (abs_dec <= prm.absoluteErrorTol)
+            current = new_error
+            if rep.status == 2 or converged or not math.isfinite(current):
+                if converged and rep.status != 2:
+                    rep.status = 0
+                break
+        torch.cuda.synchronize(self.P.device)
+        rep.seconds = time.perf_counter() - t0
+        rep.final_error, rep.final_lambda = current, lam
+        return poses, vels, bias, points, rep

@@ -187,6 +187,8 @@ __device__ __forceinline__ void stereo_factor(const double* __restrict__ T, cons
   }
 }
 
+__host__ __device__ __forceinline__ int pose_stride(const vus_ba_problem& P) { return P.pose_stride > 1 ? P.pose_stride : 1; }
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -314,7 +316,7 @@ __global__ void priors_kernel(vus_ba_problem P, const double* __restrict__ poses
         Hpp[36 * (size_t)i + 7 * k] += w * w;
         gp[6 * (size_t)i + k] += w * r;
       }
-      if (mode == 2) r += w * dp[6 * (size_t)i + k];
+      if (mode == 2) r += w * dp[6 * (size_t)pose_stride(P) * i + k];
       e += 0.5 * r * r;
     }
   }
@@ -370,17 +372,17 @@ __global__ void ymul_kernel(vus_ba_problem P, const double* __restrict__ W, cons
 }
 
 // diagonal blocks S_ii = Hpp_i + lambda I (the band was zeroed before)
-__global__ void schur_init_kernel(int n_poses, int band, double lambda, const double* __restrict__ Hpp,
+__global__ void schur_init_kernel(int n_poses, int band, int ps, double lambda, const double* __restrict__ Hpp,
                                   double* __restrict__ Sband) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t >= 36 * n_poses) return;
   const int i = t / 36, e = t - 36 * i;
-  Sband[36 * (size_t)i * (band + 1) + e] = Hpp[t] + ((e % 7 == 0) ? lambda : 0.0);
+  Sband[36 * (size_t)(ps * i) * (band + 1) + e] = Hpp[t] + ((e % 7 == 0) ? lambda : 0.0);
 }
 
 // One wave per non-zero block (i,k): S_ik -= sum_pairs Y_a W_b^T.
 // 60 lanes = 5 pair slices x 12 strips (row r, three columns); slices are summed in a fixed order.
-__global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, const double* __restrict__ W,
+__global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, int ps, const double* __restrict__ W,
                                                            const double* __restrict__ Y,
                                                            double* __restrict__ Sband) {
   const int lane = threadIdx.x & 63;
@@ -409,7 +411,7 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, c
     t2 += __shfl(acc2, within + 12 * s);
   }
   if (lane < 12) {
-    double* blk = Sband + 36 * ((size_t)i * (S.band + 1) + (i - k)) + 6 * r + 3 * ch;
+    double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k)) + 6 * r + 3 * ch;
     blk[0] -= t0;
     blk[1] -= t1;
     blk[2] -= t2;
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const d
   }
 #pragma unroll
   for (int rr = 0; rr < 6; ++rr) acc[rr] = wave_sum(acc[rr]);
-  if (lane < 6) gs[6 * (size_t)i + lane] = gp[6 * (size_t)i + lane] - acc[lane];
+  if (lane < 6) gs[6 * (size_t)pose_stride(P) * i + lane] = gp[6 * (size_t)i + lane] - acc[lane];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -476,15 +478,18 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
 // column step is 12 FMAs per lane.  The pivot column travels through a double-buffered LDS vector:
 // one barrier per step.
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
-                                                         double* __restrict__ yv, int* __restrict__ status) {
+                                                         double* __restrict__ yv, size_t ystride, int n_rhs,
+                                                         int* __restrict__ status) {
   __shared__ double s_l[2][64];
   __shared__ int s_bad;
   constexpr int NJ = NB / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
-  const int R = lane;                 // rows 0..nb-1: block rows; row nb: the right-hand side
+  const int R = lane;                 // rows 0..nb-1: block rows; rows nb..nb+n_rhs-1: the right-hand sides
   const int ii = R / 6, rr = R - 6 * ii;
+  const bool is_rhs = R >= nb && R < nb + n_rhs;
+  double* yrow = yv + (size_t)(is_rhs ? R - nb : 0) * ystride + 6 * (size_t)k0;
   if (threadIdx.x == 0) s_bad = 0x7FFFFFFF;
   double row[NJ];
 #pragma unroll
@@ -492,7 +497,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb
     const int C = 4 * j + wave, kk = C / 6, cc = C - 6 * kk;
     double v = 0.0;
     if (R < nb && kk <= ii && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * rr + cc];
-    if (R == nb && C < nb) v = yv[6 * (size_t)k0 + C];
+    if (is_rhs && C < nb) v = yrow[C];
     row[j] = v;
   }
   __syncthreads();
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb
     const int C = 4 * j + wave, kk = C / 6, cc = C - 6 * kk;
     if (R < nb && kk <= ii && ii - kk <= band)
       blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * rr + cc] = (C <= R) ? row[j] : 0.0;   // strict upper part of the diagonal blocks = 0
-    if (R == nb && C < nb) yv[6 * (size_t)k0 + C] = row[j];
+    if (is_rhs && C < nb) yrow[C] = row[j];
   }
 }
 
@@ -634,7 +639,7 @@ constexpr int ULD = NB + 1;       // LDS row stride (doubles)
 typedef double double4_t __attribute__((ext_vector_type(4)));
 
 __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
-                                                          double* __restrict__ yv) {
+                                                          double* __restrict__ yv, size_t ystride, int n_rhs) {
   __shared__ double Xi[UT * ULD];
   __shared__ double Xj[UT * ULD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -706,11 +711,13 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ S
   }
   if (ti == tj && tid < UT) {
     const int i = pi0 + tid / 6;
-    if (i <= i_last) {
-      double acc = 0.0;
-      for (int c = 0; c < nb; ++c) acc += Xi[tid * ULD + c] * yv[6 * (size_t)k0 + c];
-      yv[6 * (size_t)i + (tid % 6)] -= acc;
-    }
+    if (i <= i_last)
+      for (int q = 0; q < n_rhs; ++q) {
+        double* yq = yv + (size_t)q * ystride;
+        double acc = 0.0;
+        for (int c = 0; c < nb; ++c) acc += Xi[tid * ULD + c] * yq[6 * (size_t)k0 + c];
+        yq[6 * (size_t)i + (tid % 6)] -= acc;
+      }
   }
 }
 
@@ -719,15 +726,18 @@ __global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ S
 // threads subtract the panel's contribution from the rows above it.  y lives in LDS when it fits.
 constexpr int BS_THREADS = 1024;
 constexpr int BS_LDS_N = 12288;
+constexpr int BS_MAX_RHS = 8;
 __global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(const double* __restrict__ Sb, int n_poses,
-                                                                    int band, double* __restrict__ yv) {
+                                                                    int band, double* __restrict__ yv, size_t ystride,
+                                                                    int n_rhs) {
   extern __shared__ double s_y[];
   __shared__ double s_L[NB * LDD];
-  __shared__ double s_x[NB];
+  __shared__ double s_x[BS_MAX_RHS][NB];
   const int tid = threadIdx.x;
   const int n = 6 * n_poses;
-  const bool in_lds = n <= BS_LDS_N;
+  const bool in_lds = n_rhs == 1 && n <= BS_LDS_N;   // single right-hand side: keep it in LDS
   double* y = in_lds ? s_y : yv;
+  const size_t ys = in_lds ? 0 : ystride;
   if (in_lds)
     for (int t = tid; t < n; t += BS_THREADS) s_y[t] = yv[t];
   const int n_panels = (n_poses + PB - 1) / PB;
@@ -742,27 +752,39 @@ __global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(const double
       s_L[R * LDD + C] = (R == C) ? 1.0 / v : v;   // the diagonal is stored inverted
     }
     __syncthreads();
-    if (tid < 64) {
-      double yr = tid < nb ? y[6 * k0 + tid] : 0.0;
+    if (tid < 64 * n_rhs) {   // wave q solves right-hand side q
+      const int q = tid >> 6, lane = tid & 63;
+      double* yq = y + (size_t)q * ys;
+      double yr = lane < nb ? yq[6 * k0 + lane] : 0.0;
       for (int c = nb - 1; c >= 0; --c) {     // L^T x = y: x_c = y_c / L_cc, then y_r -= L_cr x_c for r < c
         const double xc = bcast_lane(yr, c) * s_L[c * LDD + c];
-        if (tid == c) yr = xc;
-        else if (tid < c) yr -= s_L[c * LDD + tid] * xc;
+        if (lane == c) yr = xc;
+        else if (lane < c) yr -= s_L[c * LDD + lane] * xc;
       }
-      if (tid < nb) { y[6 * k0 + tid] = yr; s_x[tid] = yr; }
+      if (lane < nb) { yq[6 * k0 + lane] = yr; s_x[q][lane] = yr; }
     }
     __syncthreads();
     const int i0 = max(0, k0 - band);   // rows above the panel that hold a block in some panel row
     for (int t = tid; t < 6 * (k0 - i0); t += BS_THREADS) {
       const int i = i0 + t / 6, c = t % 6;
-      double acc = 0.0;
+      double acc[BS_MAX_RHS];
+#pragma unroll
+      for (int q = 0; q < BS_MAX_RHS; ++q) acc[q] = 0.0;
       for (int kk = 0; kk < pb; ++kk) {
         if (k0 + kk - i > band) break;
         const double* Lki = blk_ptr(Sb, band, k0 + kk, i) + c;
+        double l[6];
 #pragma unroll
-        for (int r = 0; r < 6; ++r) acc += Lki[6 * r] * s_x[6 * kk + r];
+        for (int r = 0; r < 6; ++r) l[r] = Lki[6 * r];
+#pragma unroll
+        for (int q = 0; q < BS_MAX_RHS; ++q)
+          if (q < n_rhs)
+#pragma unroll
+            for (int r = 0; r < 6; ++r) acc[q] += l[r] * s_x[q][6 * kk + r];
       }
-      y[6 * i + c] -= acc;
+#pragma unroll
+      for (int q = 0; q < BS_MAX_RHS; ++q)
+        if (q < n_rhs) y[(size_t)q * ys + 6 * i + c] -= acc[q];
     }
     __syncthreads();
   }
@@ -792,7 +814,7 @@ __global__ __launch_bounds__(256) void backsub_kernel(vus_ba_problem P, const do
   double t[3] = {0, 0, 0};
   for (int a = P.point_ptr[j] + lane; a < P.point_ptr[j + 1]; a += 64) {
     const double* Wa = W + 18 * (size_t)P.obs_ppos[a];
-    const double* d = dp + 6 * (size_t)P.obs_pose[a];
+    const double* d = dp + 6 * (size_t)pose_stride(P) * P.obs_pose[a];
 #pragma unroll
     for (int rr = 0; rr < 6; ++rr) {
       const double dr = d[rr];
@@ -813,7 +835,7 @@ __global__ __launch_bounds__(256) void backsub_kernel(vus_ba_problem P, const do
   }
 }
 
-__global__ void retract_kernel(int n_poses, int n_points, const double* __restrict__ poses,
+__global__ void retract_kernel(int n_poses, int n_points, int ps, const double* __restrict__ poses,
                                const double* __restrict__ points, const double* __restrict__ dp,
                                const double* __restrict__ dl, double* __restrict__ new_poses,
                                double* __restrict__ new_points) {
@@ -822,7 +844,7 @@ __global__ void retract_kernel(int n_poses, int n_points, const double* __restri
     double T[12], xi[6], out[12];
     load12(poses + 12 * (size_t)t, T);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) xi[k] = dp[6 * (size_t)t + k];
+    for (int k = 0; k < 6; ++k) xi[k] = dp[6 * (size_t)ps * t + k];
     pose_retract(T, xi, out);
 #pragma unroll
     for (int k = 0; k < 12; ++k) new_poses[12 * (size_t)t + k] = out[k];
@@ -864,7 +886,7 @@ __global__ __launch_bounds__(256) void eval_points_kernel(vus_ba_problem P, cons
       double H1[18], H2[9];
       load12(poses + 12 * (size_t)i, T);
       stereo_factor<true, true>(T, po, m, K, r, H1, H2);
-      const double* d = dp + 6 * (size_t)i;
+      const double* d = dp + 6 * (size_t)pose_stride(P) * i;
 #pragma unroll
       for (int rr = 0; rr < 3; ++rr) {
         double t = r[rr];
@@ -941,18 +963,20 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
                             double* Y, double* Sband, double* gs, void* stream) {
   if (int rc = check_problem(P)) return rc;
   VUS_REQUIRE(S != nullptr, "structure is null");
-  VUS_REQUIRE(S->band >= 0 && S->band < P->n_poses + 1 && S->n_blocks >= 0 && S->n_pairs >= 0,
+  VUS_REQUIRE(S->band >= 0 && S->band < pose_stride(*P) * P->n_poses + 1 && S->n_blocks >= 0 && S->n_pairs >= 0,
               "bad structure: band=%d blocks=%d pairs=%d", S->band, S->n_blocks, S->n_pairs);
   VUS_REQUIRE(W && V && gl && Hpp && gp && Vinv && Y && Sband && gs, "null buffer");
   if (S->n_blocks > 0) VUS_REQUIRE(S->blk_ptr && S->blk_i && S->blk_k && S->pair_a && S->pair_b, "structure arrays are null");
   VUS_REQUIRE(lambda >= 0.0, "lambda=%g", lambda);
   hipStream_t st = vus::as_stream(stream);
   const int nP = P->n_poses, nL = P->n_points, nO = P->n_obs;
-  VUS_CHECK_HIP(hipMemsetAsync(Sband, 0, sizeof(double) * 36 * (size_t)nP * (S->band + 1), st));
+  const int ps = pose_stride(*P);
+  VUS_CHECK_HIP(hipMemsetAsync(Sband, 0, sizeof(double) * 36 * (size_t)nP * ps * (S->band + 1), st));
+  if (ps > 1) VUS_CHECK_HIP(hipMemsetAsync(gs, 0, sizeof(double) * 6 * (size_t)nP * ps, st));
   if (nL > 0) vinv_kernel<<<cdiv(nL, 256), 256, 0, st>>>(nL, lambda, V, Vinv);
   if (nO > 0) ymul_kernel<<<cdiv(nO, 256), 256, 0, st>>>(*P, W, Vinv, Y);
-  schur_init_kernel<<<cdiv(36ll * nP, 256), 256, 0, st>>>(nP, S->band, lambda, Hpp, Sband);
-  if (S->n_blocks > 0) schur_blocks_kernel<<<cdiv(S->n_blocks, 4), 256, 0, st>>>(*S, W, Y, Sband);
+  schur_init_kernel<<<cdiv(36ll * nP, 256), 256, 0, st>>>(nP, S->band, ps, lambda, Hpp, Sband);
+  if (S->n_blocks > 0) schur_blocks_kernel<<<cdiv(S->n_blocks, 4), 256, 0, st>>>(*S, ps, W, Y, Sband);
   schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, Y, gl, gp, gs);
   VUS_CHECK_LAUNCH("ba_schur");
   return VUS_OK;
@@ -966,34 +990,49 @@ extern "C" int vus_ba_add_diag(double* Sband, int n_poses, int band, double valu
   return VUS_OK;
 }
 
+namespace {
+int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, int* status, hipStream_t st) {
+  const int n = 6 * n_nodes;
+  const size_t ystride = (size_t)n;
+  VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+  for (int k0 = 0; k0 < n_nodes; k0 += PB) {
+    chol_panel_kernel<<<1, 256, 0, st>>>(Sband, n_nodes, band, k0, y, ystride, n_rhs, status);
+    const int pb = n_nodes - k0 < PB ? n_nodes - k0 : PB;
+    const int i_first = k0 + pb;
+    int i_last = k0 + pb - 1 + band;
+    if (i_last > n_nodes - 1) i_last = n_nodes - 1;
+    const int rows = i_last - i_first + 1;
+    if (rows > 0) {
+      chol_trsm_kernel<<<cdiv(6ll * rows, TRSM_T), TRSM_T, 0, st>>>(Sband, n_nodes, band, k0);
+      const int tiles = (rows + UTP - 1) / UTP;
+      chol_update_kernel<<<tiles * (tiles + 1) / 2, 256, 0, st>>>(Sband, n_nodes, band, k0, y, ystride, n_rhs);
+    }
+  }
+  const size_t lds = (n_rhs == 1 && n <= BS_LDS_N) ? sizeof(double) * (size_t)n : 0;
+  if (lds > 48 * 1024)  // more than the default dynamic-LDS allowance: gfx950 has 160 KiB per workgroup
+    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  chol_backsolve_kernel<<<1, BS_THREADS, lds, st>>>(Sband, n_nodes, band, y, ystride, n_rhs);
+  VUS_CHECK_LAUNCH("ba_band_solve");
+  return VUS_OK;
+}
+}  // namespace
+
 extern "C" int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, double* dp, int* status,
                                  void* stream) {
   VUS_REQUIRE(Sband && gs && dp && status, "null buffer");
   VUS_REQUIRE(n_poses >= 1 && band >= 0, "n_poses=%d band=%d", n_poses, band);
   hipStream_t st = vus::as_stream(stream);
-  const int n = 6 * n_poses;
-  VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
-  negate_copy_kernel<<<cdiv(n, 256), 256, 0, st>>>(gs, dp, n);
-  for (int k0 = 0; k0 < n_poses; k0 += PB) {
-    chol_panel_kernel<<<1, 256, 0, st>>>(Sband, n_poses, band, k0, dp, status);
-    const int pb = n_poses - k0 < PB ? n_poses - k0 : PB;
-    const int i_first = k0 + pb;
-    int i_last = k0 + pb - 1 + band;
-    if (i_last > n_poses - 1) i_last = n_poses - 1;
-    const int rows = i_last - i_first + 1;
-    if (rows > 0) {
-      chol_trsm_kernel<<<cdiv(6ll * rows, TRSM_T), TRSM_T, 0, st>>>(Sband, n_poses, band, k0);
-      const int tiles = (rows + UTP - 1) / UTP;
-      chol_update_kernel<<<tiles * (tiles + 1) / 2, 256, 0, st>>>(Sband, n_poses, band, k0, dp);
-    }
-  }
-  const size_t lds = n <= BS_LDS_N ? sizeof(double) * (size_t)n : 0;
-  if (lds > 48 * 1024)  // more than the default dynamic-LDS allowance: gfx950 has 160 KiB per workgroup
-    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  chol_backsolve_kernel<<<1, BS_THREADS, lds, st>>>(Sband, n_poses, band, dp);
-  VUS_CHECK_LAUNCH("ba_band_solve");
-  return VUS_OK;
+  negate_copy_kernel<<<cdiv(6ll * n_poses, 256), 256, 0, st>>>(gs, dp, 6 * n_poses);
+  return band_solve_impl(Sband, n_poses, band, dp, 1, status, st);
+}
+
+extern "C" int vus_ba_band_solve_multi(double* Sband, int n_nodes, int band, double* rhs, int n_rhs, int* status,
+                                       void* stream) {
+  VUS_REQUIRE(Sband && rhs && status, "null buffer");
+  VUS_REQUIRE(n_nodes >= 1 && band >= 0, "n_nodes=%d band=%d", n_nodes, band);
+  VUS_REQUIRE(n_rhs >= 1 && n_rhs <= BS_MAX_RHS, "n_rhs=%d out of range [1, %d]", n_rhs, BS_MAX_RHS);
+  return band_solve_impl(Sband, n_nodes, band, rhs, n_rhs, status, vus::as_stream(stream));
 }
 
 extern "C" int vus_ba_backsub(const vus_ba_problem* P, const double* W, const double* Vinv, const double* gl,
@@ -1013,7 +1052,7 @@ extern "C" int vus_ba_eval_step(const vus_ba_problem* P, const double* poses, co
   VUS_REQUIRE(poses && points && dp && dl && new_poses && new_points && out && work, "null buffer");
   hipStream_t st = vus::as_stream(stream);
   const int nP = P->n_poses, nL = P->n_points;
-  retract_kernel<<<cdiv(nP > nL ? nP : (nL < 65536 ? nL : 65536), 256) + 1, 256, 0, st>>>(nP, nL, poses, points, dp, dl,
+  retract_kernel<<<cdiv(nP > nL ? nP : (nL < 65536 ? nL : 65536), 256) + 1, 256, 0, st>>>(nP, nL, pose_stride(*P), poses, points, dp, dl,
                                                                                            new_poses, new_points);
   double* part_lin = work;
   double* part_new = work + (nL + 1);
