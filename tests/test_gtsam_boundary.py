@@ -94,7 +94,7 @@ def mini_batch_create(seq, with_imu=False):
         initial_estimate.insert(X(i), pose)                                          # :283/:287
         initial_estimate.insert(V(i), velocity)                                      # :284/:288
         if i > 0 and with_imu:
-            pim.integrateMeasurement(np.zeros(3), np.zeros(3), 0.005)                 # :290
+            pim.integrateMeasurement(np.array([0.0, 0.0, 9.81]), np.zeros(3), 0.005)  # :290
             graph.push_back(ImuFactor(X(i - 1), V(i - 1), X(i), V(i), B(0), pim))     # :291
             pim.resetIntegration()                                                    # :293
         for a in by_pose.get(i, []):                                                  # :296 (all keyframes: see DESIGN.md)
@@ -133,9 +133,10 @@ def test_pack_graph_matches_sequence_arrays():
 
 def test_unsupported_factors_fail_loudly_at_optimize_time():
     seq = synth.ba_sequence(6, 30, 10)
-    graph, initial = mini_batch_create(seq, with_imu=True)             # constructing and adding is fine...
-    with pytest.raises(NotImplementedError, match="ImuFactor"):
-        _pack_graph(graph, initial)                                   # ...solving is refused, loudly
+    graph, initial = mini_batch_create(seq, with_imu=True)             # inertial factors pack into the nav side
+    pg = _pack_graph(graph, initial)
+    assert pg["nav"] is not None and len(pg["nav"]["imu"][0]) == 5 and pg["nav"]["vprior"][0].tolist() == [0]
+    assert pg["aux"].keys == []
     g = NonlinearFactorGraph()
     g.push_back(gtsam.CustomFactor(gtsam.noiseModel.Isotropic.Sigma(3, 0.1), [V(1), X(1)], lambda *a: None))
     with pytest.raises(NotImplementedError, match="CustomFactor"):

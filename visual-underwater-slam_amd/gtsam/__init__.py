@@ -10,10 +10,10 @@ module exposes the same names with the same argument meaning, so that
 is the only change batch.py needs for the stereo path; `LevenbergMarquardtOptimizer.optimize()` then
 runs on the MI355X kernels (ba.py / csrc/ba.hip).
 
-Scope: GenericStereoFactor3D, PriorFactorPose3 and prior factors on vector
-variables are solved.  ImuFactor / CustomFactor objects can be constructed and added (so batch.py's
-graph-building code runs unchanged) but optimize() refuses a graph that contains them, loudly:
-those are the "next" rows f1/f2, not built yet.
+Scope: GenericStereoFactor3D, PriorFactorPose3, PriorFactorVector, ImuFactor (with
+PreintegratedImuMeasurements) and the DVL velocity factor (DvlVelocityFactor, the well-formed
+replacement of the reference's CustomFactor) are solved on the GPU.  A generic gtsam.CustomFactor
+(arbitrary Python callback) can be constructed and added, but optimize() refuses it, loudly.
 
 Host-side classes here hold plain numpy values; no BA arithmetic happens in Python.
 Errors surface as RuntimeError, as pybind11 does for gtsam's C++ exceptions.
@@ -29,7 +29,7 @@ from .symbol_shorthand import symbol, symbolChr, symbolIndex  # noqa: F401
 __all__ = [
     "Point3", "Rot3", "Pose3", "Cal3_S2Stereo", "Cal3_S2", "StereoPoint2", "noiseModel", "imuBias",
     "GenericStereoFactor3D", "PriorFactorPose3", "PriorFactorVector", "PriorFactorPoint3",
-    "PriorFactorConstantBias", "BetweenFactorConstantBias", "ImuFactor", "CustomFactor",
+    "PriorFactorConstantBias", "BetweenFactorConstantBias", "ImuFactor", "CustomFactor", "DvlVelocityFactor",
     "PreintegrationParams", "PreintegratedImuMeasurements", "NavState", "ISAM2",
     "NonlinearFactorGraph", "Values", "LevenbergMarquardtParams", "LevenbergMarquardtOptimizer",
     "StereoFactorBlock", "symbol_shorthand", "symbol",
@@ -451,28 +451,64 @@ class PreintegrationParams:
 
 
 class PreintegratedImuMeasurements:
-    """Records the raw samples (batch.py:290) so an ImuFactor can copy them; the preintegration
-    arithmetic itself belongs to row f1 of SURVEY.md section 8 and is not implemented yet."""
+    """gtsam.PreintegratedImuMeasurements(params, bias): on-manifold preintegration of the raw samples
+    (batch.py:91,290,293), done on the host at graph-build time exactly like GTSAM does (imu.py)."""
 
     def __init__(self, params: PreintegrationParams, bias: Optional[_ConstantBias] = None):
+        from .imu import Preintegrator
         self.params, self.bias = params, bias or _ConstantBias()
-        self.samples: List[np.ndarray] = []
+        self._pre = Preintegrator(self.bias.vector(), params.accelerometerCovariance, params.gyroscopeCovariance,
+                                  params.integrationCovariance)
 
     def integrateMeasurement(self, acc, gyro, dt):
-        self.samples.append(np.concatenate([np.asarray(acc, float), np.asarray(gyro, float), [float(dt)]]))
+        self._pre.integrate(acc, gyro, dt)
 
     def resetIntegration(self):
-        self.samples = []
+        self._pre.reset()
 
     def deltaTij(self):
-        return float(sum(s[6] for s in self.samples))
+        return float(self._pre.dt)
+
+    def deltaRij(self):
+        return Rot3(self._pre.dR)
+
+    def deltaPij(self):
+        return self._pre.dP.copy()
+
+    def deltaVij(self):
+        return self._pre.dV.copy()
+
+    def preintMeasCov(self):
+        return self._pre.cov.copy()
 
 
 class ImuFactor(_Factor):
-    def __init__(self, pose_i, vel_i, pose_j, vel_j, bias, pim: PreintegratedImuMeasurements):   # batch.py:238
+    """ImuFactor(pose_i, vel_i, pose_j, vel_j, bias, pim)  (batch.py:238).  Like gtsam, the factor copies the
+    preintegrated measurement at construction, so resetIntegration() right after (batch.py:293) is safe."""
+
+    def __init__(self, pose_i, vel_i, pose_j, vel_j, bias, pim: PreintegratedImuMeasurements):
         super().__init__([pose_i, vel_i, pose_j, vel_j, bias])
-        self.samples = [s.copy() for s in pim.samples]     # gtsam copies the PIM: resetIntegration() after is safe
-        self.params = pim.params
+        if pim._pre.dt <= 0.0:
+            raise RuntimeError("ImuFactor: the preintegrated interval is empty (no IMU sample between the keyframes)")
+        if pim.params.use2ndOrderCoriolis or np.any(pim.params.omegaCoriolis != 0):
+            raise NotImplementedError("Coriolis terms are not implemented (batch.py:186-187 disables them)")
+        self.pim = pim._pre.packed()
+        self.W = pim._pre.whitening().reshape(-1)
+        self.gravity = np.asarray(pim.params.n_gravity, dtype=float).copy()
+
+
+class DvlVelocityFactor(_Factor):
+    """EXTENSION replacing the reference's DVL gtsam.CustomFactor (batch.py:196-250): same residual
+    e = R_i * m - v_i on keys (V(i), X(i)), with the correct Jacobians (the callback of the reference returns
+    3x3 Jacobians for a 6-dof Pose3 key, which no solver can use: SURVEY.md D7).
+    DvlVelocityFactor(noiseModel, V(i), X(i), measured_body_velocity)."""
+
+    def __init__(self, model: _NoiseModel, velKey: int, poseKey: int, measured):
+        super().__init__([velKey, poseKey])
+        if model.dim() != 3 or not model.is_isotropic():
+            raise NotImplementedError("DvlVelocityFactor needs an isotropic 3-dimensional noise model (batch.py:98)")
+        self._model = model
+        self.measured = np.asarray(measured, dtype=float).reshape(3).copy()
 
 
 class CustomFactor(_Factor):

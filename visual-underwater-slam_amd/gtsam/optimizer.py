@@ -95,8 +95,9 @@ class _AuxPriors:
 def _pack_graph(graph, values):
     """Factor graph + Values -> arrays for StereoBAProblem.  Raises on anything outside the built scope."""
     from . import (GenericStereoFactor3D, StereoFactorBlock, PriorFactorPose3, PriorFactorVector, Pose3,
-                   ImuFactor, CustomFactor)
+                   ImuFactor, CustomFactor, DvlVelocityFactor, _ConstantBias)
     meas, pkeys, lkeys = [], [], []
+    imu_f, dvl_f = [], []
     model_sigma, calib = None, None
     prior_pose, prior_vec = [], []
     single_m, single_p, single_l = [], [], []
@@ -123,10 +124,15 @@ def _pack_graph(graph, values):
             prior_pose.append(f)
         elif isinstance(f, PriorFactorVector):
             prior_vec.append(f)
-        elif isinstance(f, (ImuFactor, CustomFactor)):
+        elif isinstance(f, ImuFactor):
+            imu_f.append(f)
+        elif isinstance(f, DvlVelocityFactor):
+            dvl_f.append(f)
+        elif isinstance(f, CustomFactor):
             raise NotImplementedError(
-                f"{type(f).__name__} is not built yet (SURVEY.md section 8, rows f1/f2): this round solves graphs of "
-                "GenericStereoFactor3D + PriorFactorPose3 (+ decoupled PriorFactorVector) on the GPU")
+                "gtsam.CustomFactor (a Python callback per factor) cannot run on the GPU; the reference's DVL factor "
+                "(batch.py:241-250) additionally returns ill-formed Jacobians (SURVEY.md D7): use "
+                "gtsam.DvlVelocityFactor(noise, V(i), X(i), measurement) instead")
         else:
             raise NotImplementedError(f"factor type {type(f).__name__} is not supported by the MI355X optimizer")
     if single_m:
@@ -162,6 +168,9 @@ def _pack_graph(graph, values):
         if j >= len(pose_keys) or pose_keys[j] != k:
             raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(k)}\", which does not exist in the Values.")
         pr_idx.append(j); pr_T.append(f._prior.flat12()); pr_s.append(f._model.sigmas())
+    nav = None
+    if imu_f or dvl_f:
+        nav, prior_vec = _pack_nav(values, pose_keys, imu_f, dvl_f, prior_vec)
     aux = _AuxPriors()
     lm_set = set(lm_keys.tolist())
     for f in prior_vec:
@@ -177,14 +186,72 @@ def _pack_graph(graph, values):
                 points=points, sigma=model_sigma if model_sigma is not None else 1.0,
                 K=calib.vector6() if calib is not None else np.array([1.0, 1.0, 0.0, 0.0, 0.0, 1.0]),
                 prior_idx=np.asarray(pr_idx, np.int32), prior_T=np.asarray(pr_T, float).reshape(-1, 12),
-                prior_sigmas=np.asarray(pr_s, float).reshape(-1, 6), aux=aux)
+                prior_sigmas=np.asarray(pr_s, float).reshape(-1, 6), aux=aux, nav=nav)
+
+
+def _pack_nav(values, pose_keys, imu_f, dvl_f, prior_vec):
+    """Velocity / bias side of the graph (batch.py:274-293): every pose X(i) needs a velocity V(i) with the same
+    index; one shared bias key (batch.py:238 passes B(0) to every ImuFactor)."""
+    from . import _ConstantBias
+    pidx = {int(k): i for i, k in enumerate(pose_keys.tolist())}
+    vel_keys = []
+    for k in pose_keys.tolist():
+        vk = _sym.symbol("v", _sym.symbolIndex(k))
+        if not values.exists(vk):
+            raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(vk)}\", which does not exist in the Values.")
+        vel_keys.append(vk)
+    vidx = {k: i for i, k in enumerate(vel_keys)}
+    vels = np.stack([values.atVector(k) for k in vel_keys])
+    if vels.shape[1] != 3:
+        raise RuntimeError("velocity variables must be 3-vectors")
+    bias_keys = sorted({f._keys[4] for f in imu_f})
+    if len(bias_keys) > 1:
+        raise NotImplementedError("several IMU bias variables are not supported (batch.py uses the single B(0))")
+    bias_key = bias_keys[0] if bias_keys else None
+    bias = values.atConstantBias(bias_key).vector() if bias_key is not None else np.zeros(6)
+    imu_i, imu_j, pims, Ws, grav = [], [], [], [], None
+    for f in imu_f:
+        ki, kvi, kj, kvj, _ = f._keys
+        if ki not in pidx or kj not in pidx or vidx.get(kvi) != pidx[ki] or vidx.get(kvj) != pidx[kj]:
+            raise RuntimeError("ImuFactor: its pose / velocity keys are not X(i), V(i), X(j), V(j) of the Values")
+        if pidx[kj] != pidx[ki] + 1:
+            raise NotImplementedError("ImuFactor between non-consecutive keyframes is not supported")
+        if grav is not None and not np.array_equal(grav, f.gravity):
+            raise NotImplementedError("all ImuFactors must share one gravity vector")
+        grav = f.gravity
+        imu_i.append(pidx[ki]); imu_j.append(pidx[kj]); pims.append(f.pim); Ws.append(f.W)
+    dvl_p, dvl_m, dvl_s = [], [], []
+    for f in dvl_f:
+        kv, kx = f._keys
+        if kx not in pidx or vidx.get(kv) != pidx[kx]:
+            raise RuntimeError("DvlVelocityFactor: its keys are not (V(i), X(i)) of the Values")
+        dvl_p.append(pidx[kx]); dvl_m.append(f.measured); dvl_s.append(float(f._model.sigmas()[0]))
+    vp_i, vp_v, vp_s, rest = [], [], [], []
+    for f in prior_vec:
+        k = f._keys[0]
+        if k in vidx:
+            vp_i.append(vidx[k]); vp_v.append(f._prior); vp_s.append(f._model.sigmas())
+        else:
+            rest.append(f)
+    nav = dict(vel_keys=vel_keys, bias_key=bias_key, vels=vels, bias=bias,
+               gravity=grav if grav is not None else np.array([0.0, 0.0, -9.81]),
+               imu=(np.asarray(imu_i, np.int32), np.asarray(imu_j, np.int32), np.asarray(pims, float).reshape(-1, 148),
+                    np.asarray(Ws, float).reshape(-1, 81)) if imu_f else None,
+               dvl=(np.asarray(dvl_p, np.int32), np.asarray(dvl_m, float).reshape(-1, 3), np.asarray(dvl_s, float)) if dvl_f else None,
+               vprior=(np.asarray(vp_i, np.int32), np.asarray(vp_v, float).reshape(-1, 3),
+                       np.asarray(vp_s, float).reshape(-1, 3)) if vp_i else None)
+    return nav, rest
 
 
 def _build_solver(pg, device="cuda:0"):
-    from ..ba import StereoBAProblem, StereoBASolver
+    from ..ba import StereoBAProblem, StereoBASolver, NavBASolver, NavFactors
+    nav = pg.get("nav")
     prob = StereoBAProblem(pg["pose_idx"], pg["lm_idx"], pg["meas"], len(pg["pose_keys"]), len(pg["lm_keys"]),
                            pg["K"], pg["sigma"], prior_pose=pg["prior_idx"], prior_T=pg["prior_T"],
-                           prior_sigmas=pg["prior_sigmas"], device=device)
+                           prior_sigmas=pg["prior_sigmas"], device=device, pose_stride=2 if nav else 1)
+    if nav:
+        nf = NavFactors(nav["gravity"], imu=nav["imu"], dvl=nav["dvl"], vprior=nav["vprior"], device=device)
+        return prob, NavBASolver(prob, nf)
     return prob, StereoBASolver(prob)
 
 
@@ -192,7 +259,11 @@ def graph_error(graph, values) -> float:
     import torch
     pg = _pack_graph(graph, values)
     prob, sv = _build_solver(pg)
-    e = sv.error(torch.from_numpy(pg["poses"]).to(prob.device), torch.from_numpy(pg["points"]).to(prob.device))
+    dev = prob.device
+    poses = torch.from_numpy(pg["poses"]).to(dev)
+    e = sv.error(poses, torch.from_numpy(pg["points"]).to(dev))
+    if pg.get("nav"):
+        e += sv.nav_error(poses, torch.from_numpy(pg["nav"]["vels"]).to(dev), torch.from_numpy(pg["nav"]["bias"]).to(dev))
     return e + pg["aux"].error()
 
 
@@ -209,15 +280,29 @@ class LevenbergMarquardtOptimizer:
     def optimize(self):
         """Runs LM to convergence and returns a NEW Values; the inputs are left untouched."""
         import torch
-        from . import Values, Pose3
+        from . import Values, Pose3, _ConstantBias
         pg = _pack_graph(self._graph, self._initial)
         prob, sv = _build_solver(pg, self._device)
         aux = pg["aux"] if pg["aux"].keys else None
-        poses, points, rep = sv.optimize(torch.from_numpy(pg["poses"]).to(prob.device),
-                                         torch.from_numpy(pg["points"]).to(prob.device),
-                                         self._params._to_lm(), aux=aux)
+        nav = pg.get("nav")
+        dev = prob.device
+        if nav:
+            if aux is not None:
+                raise NotImplementedError("prior factors on extra vector variables next to inertial factors are not supported")
+            poses, vels, bias, points, rep = sv.optimize(torch.from_numpy(pg["poses"]).to(dev), torch.from_numpy(nav["vels"]).to(dev),
+                                                         torch.from_numpy(nav["bias"]).to(dev),
+                                                         torch.from_numpy(pg["points"]).to(dev), self._params._to_lm())
+            vels, bias = vels.cpu().numpy(), bias.cpu().numpy()
+        else:
+            poses, points, rep = sv.optimize(torch.from_numpy(pg["poses"]).to(dev), torch.from_numpy(pg["points"]).to(dev),
+                                             self._params._to_lm(), aux=aux)
         poses, points = poses.cpu().numpy(), points.cpu().numpy()
         out = Values(self._initial)
+        if nav:
+            for k, v in zip(nav["vel_keys"], vels):
+                out._d[k] = v.copy()
+            if nav["bias_key"] is not None:
+                out._d[nav["bias_key"]] = _ConstantBias(bias[:3], bias[3:])
         for k, T in zip(pg["pose_keys"].tolist(), poses):
             out._d[k] = Pose3.from_flat12(T)
         for k, p in zip(pg["lm_keys"].tolist(), points):
