@@ -240,6 +240,8 @@ def main():
             del fe, images
             torch.cuda.empty_cache()
             out["ba"] = ba_bench.run(device)
+            # the reference's complete graph (stereo + IMU + DVL + priors) at its own plumbing size, configs[0]
+            out["ba"]["full_graph_configs0"] = ba_bench.run_full_graph(device, 50, 500, 100)
             if not a.no_cpu_baseline:
                 out["ba"]["cpu_baseline"] = ba_cpu_baseline(device)
         print(json.dumps(out), flush=True)

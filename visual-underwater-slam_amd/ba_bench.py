@@ -64,3 +64,44 @@ def run(device, n_kf=2000, n_lm=50000, obs_per_kf=1000, with_breakdown=True):
 if __name__ == "__main__":
     import json
     print(json.dumps(run(torch.device("cuda:0"))))
+
+
+def run_full_graph(device, n_kf=2000, n_lm=50000, obs_per_kf=1000):
+    """The reference's complete graph (batch.py:270-305): stereo + ImuFactor + DVL + priors, with velocities and
+    the shared bias as variables, at the configs[2] size."""
+    import numpy as np
+    from . import synth
+    from .ba import StereoBAProblem, NavBASolver, NavFactors, LMParams
+    from .gtsam.imu import Preintegrator
+    t0 = time.perf_counter()
+    s = synth.nav_sequence(n_kf, n_lm, obs_per_kf)
+    pims, Ws = [], []
+    I3 = np.eye(3)
+    for i in range(1, n_kf):
+        pre = Preintegrator(np.zeros(6), I3 * synth.IMU_ACC_COV, I3 * synth.IMU_GYRO_COV, I3 * synth.IMU_INT_COV)
+        for smp in s["imu"][i - 1]:
+            pre.integrate(smp[:3], smp[3:6], smp[6])
+        pims.append(pre.packed()); Ws.append(pre.whitening().reshape(-1))
+    gen_s = time.perf_counter() - t0
+    nL = len(s["points_gt"])
+    prob = StereoBAProblem(s["obs_pose"], s["obs_point"], s["meas"], n_kf, nL, s["K"], s["sigma"], prior_pose=[0],
+                           prior_T=s["poses_gt"][:1], prior_sigmas=s["prior_sigmas"][None], device=device, pose_stride=2)
+    nav = NavFactors(s["gravity"], imu=(np.arange(n_kf - 1), np.arange(1, n_kf), np.array(pims), np.array(Ws)),
+                     dvl=(np.arange(1, n_kf), s["dvl"][1:], np.full(n_kf - 1, 0.1)),
+                     vprior=(np.array([0]), s["vels_gt"][:1], np.full((1, 3), 0.1)), device=device)
+    sv = NavBASolver(prob, nav)
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    args = (d(s["poses_init"]), d(np.zeros_like(s["vels_gt"])), d(np.zeros(6)), d(s["points_init"]))
+    sv.optimize(*args, LMParams(maxIterations=1))
+    poses, vels, bias, points, rep = sv.optimize(*args, LMParams())
+    return {
+        "metric": "full-graph LM wall time (stereo + IMU + DVL + priors)", "value": round(rep.seconds, 4), "unit": "s",
+        "config": {"keyframes": n_kf, "landmarks": nL, "stereo_factors": prob.n_obs, "imu_factors": n_kf - 1,
+                   "dvl_factors": n_kf - 1, "camera_nodes": prob.n_nodes, "band_blocks": prob.band},
+        "lm": {"iterations": rep.iterations, "linear_solves": rep.tries, "status": rep.status,
+               "initial_error": rep.initial_error, "final_error": rep.final_error},
+        "ms_per_linear_solve": round(1e3 * rep.seconds / max(rep.tries, 1), 3),
+        "max_pose_error_m": float((poses[:, 9:].cpu() - torch.from_numpy(s["poses_gt"][:, 9:])).abs().max()),
+        "max_velocity_error_mps": float((vels.cpu() - torch.from_numpy(s["vels_gt"])).abs().max()),
+        "data_generation_s": round(gen_s, 2),
+    }
