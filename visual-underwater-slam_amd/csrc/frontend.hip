@@ -610,8 +610,12 @@ __global__ __launch_bounds__(256) void orient_rbrief_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // Brute-force Hamming: one query per lane, train descriptors staged in LDS tiles.
-constexpr int MT = 1024;  // train tile
+#ifndef VUS_MT
+#define VUS_MT 512
+#endif
+constexpr int MT = VUS_MT;  // train tile
 
+template <bool GATE>
 __global__ __launch_bounds__(256) void hamming_match_kernel(
     const uint64_t* __restrict__ desc, const uint32_t* __restrict__ kp_keys,
     const int* __restrict__ kp_count, int max_kp, int W, const int* __restrict__ q_index,
@@ -652,7 +656,7 @@ __global__ __launch_bounds__(256) void hamming_match_kernel(
         int dist = __popcll(q0 ^ s_desc[4 * j]) + __popcll(q1 ^ s_desc[4 * j + 1]) +
                    __popcll(q2 ^ s_desc[4 * j + 2]) + __popcll(q3 ^ s_desc[4 * j + 3]);
         bool ok = true;
-        if (max_dy >= 0) {
+        if (GATE) {
           int xy = s_xy[j];
           int dy = yq - (int)((unsigned)xy >> 16), dx = xq - (xy & 0xFFFF);
           ok = dy <= max_dy && dy >= -max_dy && dx >= min_disp && dx <= max_disp;
@@ -965,9 +969,12 @@ extern "C" int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, 
         desc, kp_keys, kp_count, max_kp, W, h_rows, q_index, t_index, max_dy, min_disp, max_disp, max_dist, idx_out,
         dist_out);
   } else {
-    hamming_match_kernel<<<grid, 256, 0, vus::as_stream(stream)>>>(desc, kp_keys, kp_count, max_kp, W, q_index,
-                                                                t_index, max_dy, min_disp, max_disp, max_dist,
-                                                                idx_out, dist_out);
+    if (max_dy >= 0)
+      hamming_match_kernel<true><<<grid, 256, 0, vus::as_stream(stream)>>>(
+          desc, kp_keys, kp_count, max_kp, W, q_index, t_index, max_dy, min_disp, max_disp, max_dist, idx_out, dist_out);
+    else
+      hamming_match_kernel<false><<<grid, 256, 0, vus::as_stream(stream)>>>(
+          desc, kp_keys, kp_count, max_kp, W, q_index, t_index, max_dy, min_disp, max_disp, max_dist, idx_out, dist_out);
   }
   VUS_CHECK_LAUNCH("hamming_match");
   return VUS_OK;
