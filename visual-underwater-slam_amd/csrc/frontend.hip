@@ -104,7 +104,8 @@ template <bool WRITE_SCORE, bool DETECT, bool BLUR>
 __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
     const uint8_t* __restrict__ img, int H, int W, int pitch, int thr, int border,
     uint8_t* __restrict__ score_out, uint8_t* __restrict__ blur_out,
-    uint32_t* __restrict__ cand_keys, int cand_cap, int* __restrict__ cand_count) {
+    uint32_t* __restrict__ cand_keys, int cand_cap, int* __restrict__ cand_count, int n_img, int tiles_x,
+    int tiles_per_img) {
   __shared__ uint32_t s_img[IMG_ROWS * IMG_DW];
   __shared__ uint32_t s_score[(WRITE_SCORE || DETECT) ? SC_ROWS * SC_DW : 1];
   __shared__ uint32_t s_h[BLUR ? H_ROWS * H_DW : 2];
@@ -115,8 +116,13 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
   uint32_t* const s_keys = s_img;
 
   const int tid = threadIdx.x;
-  const int n = blockIdx.z;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
+  // XCD-aware block -> (image, tile) map: blocks with equal (blockIdx % 8) share an XCD, so all tiles of one
+  // image run on ONE XCD and the halo re-reads of neighbouring tiles hit its L2 instead of HBM (speed only).
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n = (slot / tiles_per_img) * 8 + xcd;
+  if (n >= n_img) return;
+  const int tile = slot - (slot / tiles_per_img) * tiles_per_img;
+  const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
   const uint8_t* im = img + (size_t)n * H * pitch;
 
   // stage the tile as dwords; out-of-image pixels replicate the border (what the smoothing wants;
@@ -866,14 +872,21 @@ __global__ void triangulate_kernel(const double* __restrict__ feat, int n, const
 
 int check_image_args(const void* img, int n_img, int H, int W, int pitch) {
   VUS_REQUIRE(img != nullptr, "image pointer is null");
-  VUS_REQUIRE(n_img >= 0 && n_img <= 65535, "n_img=%d out of range [0, 65535]", n_img);
+  VUS_REQUIRE(n_img >= 0 && n_img <= (1 << 20), "n_img=%d out of range [0, 2^20]", n_img);
   VUS_REQUIRE(H >= 7 && W >= 7, "image %dx%d too small (need >= 7x7)", W, H);
   VUS_REQUIRE(pitch >= W, "pitch %d < W %d", pitch, W);
   VUS_REQUIRE((long long)H * W <= (1ll << VUS_KEY_POS_BITS), "H*W=%lld exceeds 2^24", (long long)H * W);
   return VUS_OK;
 }
 
-dim3 tile_grid(int n_img, int H, int W) { return dim3((W + TW - 1) / TW, (H + TH - 1) / TH, n_img); }
+struct TileGrid {
+  unsigned blocks;
+  int tiles_x, tiles_per_img;
+};
+TileGrid tile_grid(int n_img, int H, int W) {
+  const int tx = (W + TW - 1) / TW, ty = (H + TH - 1) / TH;
+  return TileGrid{(unsigned)(((n_img + 7) / 8) * 8 * tx * ty), tx, tx * ty};
+}
 
 }  // namespace
 
@@ -883,8 +896,9 @@ extern "C" int vus_fast_score(const uint8_t* img, int n_img, int H, int W, int p
   VUS_REQUIRE(score_out != nullptr, "score_out is null");
   VUS_REQUIRE(thr >= 1 && thr <= 254, "thr=%d out of range [1, 254]", thr);
   if (n_img == 0) return VUS_OK;
-  fast_tile_kernel<true, false, false><<<tile_grid(n_img, H, W), NTHREADS, 0, vus::as_stream(stream)>>>(
-      img, H, W, pitch, thr, 0, score_out, nullptr, nullptr, 0, nullptr);
+  const TileGrid g = tile_grid(n_img, H, W);
+  fast_tile_kernel<true, false, false><<<g.blocks, NTHREADS, 0, vus::as_stream(stream)>>>(
+      img, H, W, pitch, thr, 0, score_out, nullptr, nullptr, 0, nullptr, n_img, g.tiles_x, g.tiles_per_img);
   VUS_CHECK_LAUNCH("fast_score");
   return VUS_OK;
 }
@@ -893,8 +907,9 @@ extern "C" int vus_blur7(const uint8_t* img, int n_img, int H, int W, int pitch,
   if (int rc = check_image_args(img, n_img, H, W, pitch)) return rc;
   VUS_REQUIRE(out != nullptr, "out is null");
   if (n_img == 0) return VUS_OK;
-  fast_tile_kernel<false, false, true><<<tile_grid(n_img, H, W), NTHREADS, 0, vus::as_stream(stream)>>>(
-      img, H, W, pitch, 1, 0, nullptr, out, nullptr, 0, nullptr);
+  const TileGrid g = tile_grid(n_img, H, W);
+  fast_tile_kernel<false, false, true><<<g.blocks, NTHREADS, 0, vus::as_stream(stream)>>>(
+      img, H, W, pitch, 1, 0, nullptr, out, nullptr, 0, nullptr, n_img, g.tiles_x, g.tiles_per_img);
   VUS_CHECK_LAUNCH("blur7");
   return VUS_OK;
 }
@@ -909,12 +924,15 @@ extern "C" int vus_fast_detect(const uint8_t* img, int n_img, int H, int W, int 
   VUS_REQUIRE(border >= 0, "border=%d", border);
   if (n_img == 0) return VUS_OK;
   hipStream_t st = vus::as_stream(stream);
+  const TileGrid g = tile_grid(n_img, H, W);
   if (blur_out)
-    fast_tile_kernel<false, true, true><<<tile_grid(n_img, H, W), NTHREADS, 0, st>>>(
-        img, H, W, pitch, thr, border, nullptr, blur_out, cand_keys, cand_cap, cand_count);
+    fast_tile_kernel<false, true, true><<<g.blocks, NTHREADS, 0, st>>>(
+        img, H, W, pitch, thr, border, nullptr, blur_out, cand_keys, cand_cap, cand_count, n_img, g.tiles_x,
+        g.tiles_per_img);
   else
-    fast_tile_kernel<false, true, false><<<tile_grid(n_img, H, W), NTHREADS, 0, st>>>(
-        img, H, W, pitch, thr, border, nullptr, nullptr, cand_keys, cand_cap, cand_count);
+    fast_tile_kernel<false, true, false><<<g.blocks, NTHREADS, 0, st>>>(
+        img, H, W, pitch, thr, border, nullptr, nullptr, cand_keys, cand_cap, cand_count, n_img, g.tiles_x,
+        g.tiles_per_img);
   VUS_CHECK_LAUNCH("fast_detect");
   return VUS_OK;
 }
