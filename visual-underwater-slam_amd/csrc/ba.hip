@@ -394,13 +394,18 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, i
   const int r = within >> 1, ch = within & 1;
   double acc0 = 0, acc1 = 0, acc2 = 0;
   if (sl < 5) {
+    typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte loads from 8-byte aligned rows
     for (int p = p0 + sl; p < p1; p += 5) {
       const double* Ya = Y + 18 * (size_t)S.pair_a[p] + 3 * r;
       const double* Wb = W + 18 * (size_t)S.pair_b[p] + 9 * ch;
-      const double y0 = Ya[0], y1 = Ya[1], y2 = Ya[2];
-      acc0 += y0 * Wb[0] + y1 * Wb[1] + y2 * Wb[2];
-      acc1 += y0 * Wb[3] + y1 * Wb[4] + y2 * Wb[5];
-      acc2 += y0 * Wb[6] + y1 * Wb[7] + y2 * Wb[8];
+      const d2_t y01 = *reinterpret_cast<const d2_t*>(Ya);
+      const double y2 = Ya[2];
+      const d2_t w01 = *reinterpret_cast<const d2_t*>(Wb), w23 = *reinterpret_cast<const d2_t*>(Wb + 2),
+                 w45 = *reinterpret_cast<const d2_t*>(Wb + 4), w67 = *reinterpret_cast<const d2_t*>(Wb + 6);
+      const double w8 = Wb[8];
+      acc0 += y01.x * w01.x + y01.y * w01.y + y2 * w23.x;
+      acc1 += y01.x * w23.y + y01.y * w45.x + y2 * w45.y;
+      acc2 += y01.x * w67.x + y01.y * w67.y + y2 * w8;
     }
   }
   double t0 = 0, t1 = 0, t2 = 0;
