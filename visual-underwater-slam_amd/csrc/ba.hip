@@ -478,16 +478,26 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
   return r;
 }
 
-// Four waves, lane R of every wave = row R of the 48x48 block (row 48 = the right-hand side riding
-// along); wave w keeps the columns C = 4j + w of its rows in registers, so the rank-1 update of a
-// column step is 12 FMAs per lane.  The pivot column travels through a double-buffered LDS vector:
-// one barrier per step.
+// Four waves, lane R of every wave = row R of the 48x48 block (rows nb.. = the right-hand sides riding
+// along); wave w keeps the 6-column blocks kb = w and w + 4 of its rows in registers.  Block step s: the
+// owner wave pulls the 6x6 diagonal block into SGPRs (readlane), factors it in registers, solves its rows
+// against it and publishes them through a double-buffered LDS panel; one barrier per block step, and the
+// owner of block s+1 updates that block first and factors it while the other waves finish step s.
+__device__ __forceinline__ void panel_update(double (&blk)[6], const double (&xr)[6], const double* __restrict__ xs) {
+#pragma unroll
+  for (int c = 0; c < 6; ++c) {
+    double acc = blk[c];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) acc -= xr[k] * xs[6 * c + k];
+    blk[c] = acc;
+  }
+}
+
 __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
                                                          double* __restrict__ yv, size_t ystride, int n_rhs,
                                                          int* __restrict__ status) {
-  __shared__ double s_l[2][64];
+  __shared__ __attribute__((aligned(16))) double s_x[2][64 * 6];
   __shared__ int s_bad;
-  constexpr int NJ = NB / 4;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
@@ -496,224 +506,369 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb
   const bool is_rhs = R >= nb && R < nb + n_rhs;
   double* yrow = yv + (size_t)(is_rhs ? R - nb : 0) * ystride + 6 * (size_t)k0;
   if (threadIdx.x == 0) s_bad = 0x7FFFFFFF;
-  double row[NJ];
+  double row[2][6];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int C = 4 * j + wave, kk = C / 6, cc = C - 6 * kk;
-    double v = 0.0;
-    if (R < nb && kk <= ii && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * rr + cc];
-    if (is_rhs && C < nb) v = yrow[C];
-    row[j] = v;
+  for (int j = 0; j < 2; ++j) {
+    const int kb = wave + 4 * j;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) row[j][c] = 0.0;
+    if (R < nb && kb <= ii && ii - kb <= band) {
+      const double* src = blk_ptr(Sb, band, k0 + ii, k0 + kb) + 6 * rr;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) row[j][c] = src[c];
+    }
+    if (is_rhs && kb < pb) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) row[j][c] = yrow[6 * kb + c];
+    }
   }
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    if (c < nb) {   // uniform
-      if (wave == (c & 3)) {   // the wave that owns column c produces the pivot column
-        double d = bcast_lane(row[c >> 2], c);
-        if (!(d > 0.0)) {
-          if (lane == 0) atomicMin(&s_bad, 6 * k0 + c + 1);
-          d = 1.0;
+  for (int s = 0; s < PB; ++s) {
+    if (s < pb) {   // uniform
+      if (wave == (s & 3)) {
+        double (&a)[6] = row[s >> 2];
+        double xp[6];
+        if (s > 0) {   // look-ahead: bring this block up to date with step s-1 before factoring it
+#pragma unroll
+          for (int k = 0; k < 6; ++k) xp[k] = s_x[(s - 1) & 1][6 * lane + k];
+          panel_update(a, xp, &s_x[(s - 1) & 1][36 * s]);
         }
-        const double rs = rsqrt_newton(d);
-        const double l = (R == c) ? d * rs : row[c >> 2] * rs;
-        row[c >> 2] = l;
-        s_l[c & 1][lane] = l;
+        double D[6][6], inv[6];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = 0; c <= r; ++c) D[r][c] = bcast_lane(a[c], 6 * s + r);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double d = D[c][c];
+          if (!(d > 0.0)) {
+            if (lane == 0) atomicMin(&s_bad, 6 * k0 + 6 * s + c + 1);
+            d = 1.0;
+          }
+          const double rs = rsqrt_newton(d);
+          inv[c] = rs;
+#pragma unroll
+          for (int r = c + 1; r < 6; ++r) D[r][c] *= rs;
+#pragma unroll
+          for (int r = c + 1; r < 6; ++r)
+#pragma unroll
+            for (int c2 = c + 1; c2 <= r; ++c2) D[r][c2] -= D[r][c] * D[c2][c];
+        }
+        // x = a * L66^-T (rows of the diagonal block reproduce L66 in their lower part)
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+          double acc = a[c];
+#pragma unroll
+          for (int k = 0; k < c; ++k) acc -= a[k] * D[c][k];
+          a[c] = acc * inv[c];
+        }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) s_x[s & 1][6 * lane + k] = a[k];
+        // the step s-1 update of this wave's other block was deferred behind the factorisation
+        if (s > 0 && s < 4 && s + 4 < pb) panel_update(row[1], xp, &s_x[(s - 1) & 1][36 * (s + 4)]);
       }
       __syncthreads();
-      const double lR = s_l[c & 1][lane];
+      {
+        double xr[6];
 #pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        if (4 * j + 3 > c) {   // compile-time prune; columns C <= c of this wave are finished
-          const int C = 4 * j + wave;
-          if (C > c) row[j] -= lR * s_l[c & 1][C];   // columns C > R only touch the unused upper part
+        for (int k = 0; k < 6; ++k) xr[k] = s_x[s & 1][6 * lane + k];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int kb = wave + 4 * j;
+          // block s+1 is updated by its owner at the top of the next step
+          if (4 * j + 3 > s && kb > s + 1 && kb < pb && !(wave == ((s + 1) & 3) && s + 1 < pb))
+            panel_update(row[j], xr, &s_x[s & 1][36 * kb]);
         }
+      }
     }
   }
   __syncthreads();
   if (threadIdx.x == 0 && s_bad != 0x7FFFFFFF && status[0] == 0) status[0] = s_bad;
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) {
-    const int C = 4 * j + wave, kk = C / 6, cc = C - 6 * kk;
-    if (R < nb && kk <= ii && ii - kk <= band)
-      blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * rr + cc] = (C <= R) ? row[j] : 0.0;   // strict upper part of the diagonal blocks = 0
-    if (is_rhs && C < nb) yrow[C] = row[j];
+  for (int j = 0; j < 2; ++j) {
+    const int kb = wave + 4 * j;
+    if (R < nb && kb <= ii && ii - kb <= band) {
+      double* dst = blk_ptr(Sb, band, k0 + ii, k0 + kb) + 6 * rr;
+#pragma unroll
+      for (int c = 0; c < 6; ++c) dst[c] = (6 * kb + c <= R) ? row[j][c] : 0.0;   // strict upper part of the diagonal blocks = 0
+    }
+    if (is_rhs && kb < pb) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) yrow[6 * kb + c] = row[j][c];
+    }
   }
 }
 
-// Rows below the panel: L_row,panel = A_row,panel * L_D^-T, one scalar row per lane.  The row lives
-// in LDS transposed (Xs[column][lane]: conflict-free), L_D is read with broadcasts; the substitution
-// walks the 6x6 blocks so only 6 accumulators + 6 operands are live in registers.
-constexpr int TRSM_T = 64;
-__global__ __launch_bounds__(TRSM_T) void chol_trsm_kernel(double* __restrict__ Sb, int n_poses, int band, int k0) {
-  __shared__ double L[NB * LDD];
-  __shared__ double invd[NB];
-  __shared__ double Xs[NB * TRSM_T];
-  const int tid = threadIdx.x;
-  const int pb = min(PB, n_poses - k0);
-  const int nb = 6 * pb;
-  {
-    // all loads of the 48x48 block are issued before the first LDS store (36 independent loads per lane)
-    double v[NB * NB / TRSM_T];
-#pragma unroll
-    for (int u = 0; u < NB * NB / TRSM_T; ++u) {
-      const int t = tid + TRSM_T * u;
-      const int R = t / NB, C = t - R * NB;
-      const int ii = R / 6, kk = C / 6;
-      const bool have = R < nb && C <= R && ii - kk <= band;
-      const double* src = blk_ptr(Sb, band, k0 + (have ? ii : 0), k0) + (have ? -36 * kk + 6 * (R % 6) + (C % 6) : 0);
-      v[u] = *src;   // block (k0,k0) element 0 is always a valid address
-      if (!have) v[u] = 0.0;
-    }
-#pragma unroll
-    for (int u = 0; u < NB * NB / TRSM_T; ++u) {
-      const int t = tid + TRSM_T * u;
-      const int R = t / NB, C = t - R * NB;
-      L[R * LDD + C] = v[u];
-      if (R == C) invd[R] = (R < nb) ? 1.0 / v[u] : 1.0;
-    }
-  }
-  const int i_first = k0 + pb;
-  const int i_last = min(n_poses - 1, k0 + pb - 1 + band);
-  const int row = blockIdx.x * TRSM_T + tid;   // scalar row index inside the window
-  const int i = i_first + row / 6, rr = row % 6;
-  const bool active = i <= i_last;
-  const int kk_min = active ? max(0, i - band - k0) : PB;   // first panel pose inside this row's band
-  {
-    double a[NB];
-#pragma unroll
-    for (int kk = 0; kk < PB; ++kk) {
-      const bool have = kk >= kk_min && kk < pb;
-      const double* src = have ? blk_ptr(Sb, band, i, k0 + kk) + 6 * rr : blk_ptr(Sb, band, k0, k0);
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        a[6 * kk + c] = src[have ? c : 0];
-        if (!have) a[6 * kk + c] = 0.0;
-      }
-    }
-#pragma unroll
-    for (int c = 0; c < NB; ++c) Xs[c * TRSM_T + tid] = a[c];
-  }
-  __syncthreads();
-  // forward substitution; entries left of the band are zero and stay zero
-#pragma unroll 1
-  for (int kk = 0; kk < pb; ++kk) {
-    double t[6];
-#pragma unroll
-    for (int c = 0; c < 6; ++c) t[c] = Xs[(6 * kk + c) * TRSM_T + tid];
-#pragma unroll 1
-    for (int k2 = 0; k2 < kk; ++k2) {
-      double xv[6];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) xv[k] = Xs[(6 * k2 + k) * TRSM_T + tid];
-      const double* Lb = L + (6 * kk) * LDD + 6 * k2;
-#pragma unroll
-      for (int c = 0; c < 6; ++c)
-#pragma unroll
-        for (int k = 0; k < 6; ++k) t[c] -= xv[k] * Lb[c * LDD + k];
-    }
-    const double* Ld = L + (6 * kk) * LDD + 6 * kk;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) {
-#pragma unroll
-      for (int k = 0; k < c; ++k) t[c] -= t[k] * Ld[c * LDD + k];
-      t[c] *= invd[6 * kk + c];
-    }
-#pragma unroll
-    for (int c = 0; c < 6; ++c) Xs[(6 * kk + c) * TRSM_T + tid] = t[c];
-  }
-  for (int kk = kk_min; kk < pb; ++kk) {
-    double* b = blk_ptr(Sb, band, i, k0 + kk) + 6 * rr;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) b[c] = Xs[(6 * kk + c) * TRSM_T + tid];
-  }
-}
-
-// Trailing update of the window (SYRK): A_ij -= X_i X_j^T for window poses j <= i, where X = the
-// panel columns just produced by chol_trsm.  One workgroup per UT x UT tile of the lower triangle,
-// (UT/16)^2 MFMA tiles of 16x16 shared by 4 waves, K = 48 = 12 steps of v_mfma_f64_16x16x4_f64.
-// The right-hand side rides along: y_i -= X_i y_panel (done by the diagonal tiles).
-#ifndef VUS_UT
-#define VUS_UT 48
-#endif
-constexpr int UT = VUS_UT;        // scalar rows per tile (48 or 96)
+// Rows below the panel, fused with the trailing update.  X = A_rows,panel * L_D^-T is what a TRSM
+// kernel would write back before the SYRK A_ij -= X_i X_j^T; here every workgroup of the update
+// solves the two 48-row tiles it needs itself (the panel columns of Sband stay untouched while the
+// launch runs, so there is no ordering between workgroups to respect), and the in-place write-back of
+// X -- only the final back-substitution reads it -- rides along as extra workgroups of the NEXT
+// panel's launch.  One launch per panel instead of two, and no 1-wave-per-CU substitution kernel.
+//
+// Update tiles: one workgroup per UT x UT tile of the lower triangle, (UT/16)^2 MFMA tiles of 16x16
+// shared by 4 waves, K = 48 = 12 steps of v_mfma_f64_16x16x4_f64.  The right-hand sides ride along:
+// y_i -= X_i y_panel (done by the diagonal tiles).
+constexpr int UT = 48;            // scalar rows per tile
 constexpr int UMT = UT / 16;      // MFMA tiles per side
 constexpr int UQ = (UMT * UMT + 3) / 4;   // MFMA tiles per wave
 constexpr int UTP = UT / 6;       // poses per tile
 constexpr int ULD = NB + 1;       // LDS row stride (doubles)
 typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double d2a_t __attribute__((ext_vector_type(2), aligned(16)));
+constexpr int MLD = 17;           // LDS row stride of the 16x16 inverse blocks
 
-__global__ __launch_bounds__(256) void chol_update_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
-                                                          double* __restrict__ yv, size_t ystride, int n_rhs) {
+#ifdef VUS_TIMING
+__device__ unsigned long long g_tm[8];
+#define VUS_TMARK(n) do { if (threadIdx.x == 0 && blockIdx.x == 37) g_tm[n] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VUS_TMARK(n)
+#endif
+
+// Stage the panel's diagonal block and n_tiles (1 or 2) 48-row tiles of the panel columns in LDS (rows
+// past the window or left of the band are zero), then solve the tiles in place: X = A * L_D^-T.
+// Block forward substitution on the matrix cores, 16 columns at a time: with M_b = (16x16 diagonal
+// block b of L_D)^-1 and G_b = -M_b * L_D[row block b][columns < 16b] (written over L_D in LDS),
+//   X_b = [X_0 .. X_b-1] * G_b^T + A_b * M_b^T
+// is 4b + 4 steps of v_mfma_f64_16x16x4_f64 per 16-row tile.  A 16-row tile belongs to one wave from
+// start to end, so the three block steps need no workgroup barrier.
+__device__ __forceinline__ void stage_and_solve(const double* __restrict__ Sb, int band, int k0, int pb, int i_last,
+                                                int pose0_a, int pose0_b, int n_tiles, double* __restrict__ Xa,
+                                                double* __restrict__ Xb, double* __restrict__ sL,
+                                                double* __restrict__ sM, double* __restrict__ sInv) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    // items = (tile, scalar row lr, panel pose kk): 6 contiguous doubles each; tile 0 = the diagonal block.
+    // Every global load is in flight before the first LDS store.
+    constexpr int ITEMS = UT * PB;                 // per tile
+    constexpr int XU = (3 * ITEMS + 255) / 256;
+    d2a_t ld[XU][3];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int item = tid + 256 * u;
+      const int tile = (item >= ITEMS) + (item >= 2 * ITEMS);
+      const int e = item - ITEMS * tile;
+      const int lr = e >> 3, kk = e & 7;
+      const int ii = lr / 6, rr = lr - 6 * ii;
+      const int pose = (tile == 0 ? k0 : tile == 1 ? pose0_a : pose0_b) + ii;
+      bool have = item < (1 + n_tiles) * ITEMS && kk < pb;
+      if (tile == 0) have = have && ii < pb && kk <= ii && ii - kk <= band;
+      else have = have && pose <= i_last && kk >= pose - band - k0;
+      const double* src = have ? blk_ptr(Sb, band, pose, k0 + kk) + 6 * rr : Sb;
+      const d2a_t* s2 = reinterpret_cast<const d2a_t*>(src);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        ld[u][c] = s2[have ? c : 0];
+        if (!have) ld[u][c] = d2a_t{0.0, 0.0};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int item = tid + 256 * u;
+      const int tile = (item >= ITEMS) + (item >= 2 * ITEMS);
+      const int e = item - ITEMS * tile;
+      const int lr = e >> 3, kk = e & 7;
+      if (item < (1 + n_tiles) * ITEMS) {
+        double v[6] = {ld[u][0].x, ld[u][0].y, ld[u][1].x, ld[u][1].y, ld[u][2].x, ld[u][2].y};
+        double* dst;
+        if (tile == 0) {
+          const int ii = lr / 6, rr = lr - 6 * ii;
+          dst = sL + lr * LDD + 6 * kk;
+          if (kk == ii) {   // strict upper part of the diagonal 6x6 block is not part of L
+            double d = 1.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+              if (c == rr) d = v[c];
+              if (c > rr) v[c] = 0.0;
+            }
+            sInv[lr] = (ii < pb) ? 1.0 / d : 1.0;
+          }
+        } else {
+          dst = (tile == 1 ? Xa : Xb) + lr * ULD + 6 * kk;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dst[c] = v[c];
+      }
+    }
+  }
+  __syncthreads();
+  VUS_TMARK(1);
+  if (tid < NB) {   // column n of M_b = (16x16 diagonal block)^-1 by forward substitution (rows past nb: identity)
+    const int b = tid >> 4, n = tid & 15;
+    const double* Ld = sL + (16 * b) * LDD + 16 * b;
+    double m[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double acc = (r == n) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) acc -= Ld[r * LDD + k] * m[k];
+      m[r] = acc * sInv[16 * b + r];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sM[16 * MLD * b + MLD * r + n] = m[r];   // row-major [r][n]
+  }
+  __syncthreads();
+  VUS_TMARK(2);
+  const int arow = lane & 15, kq = lane >> 4;
+  if (wave < 3) {   // G tiles (b, kt) = (1,0), (2,0), (2,1):  -M_b * L_D[16b.., 16kt..], in place
+    const int b = wave == 0 ? 1 : 2, kt = wave == 2 ? 1 : 0;
+    const double* pm = sM + 16 * MLD * b + MLD * arow + kq;                // A operand: M_b[arow][4s + kq]
+    const double* pl = sL + (16 * b + kq) * LDD + 16 * kt + arow;     // B operand: L[16b + 4s + kq][16kt + arow]
+    double av[4], bv[4];
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) {
+      av[s2] = pm[4 * s2];
+      bv[s2] = pl[4 * s2 * LDD];
+    }
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) sL[(16 * b + kq + 4 * r) * LDD + 16 * kt + arow] = -acc[r];
+  }
+  __syncthreads();
+  VUS_TMARK(3);
+  // 16-row tiles: n_tiles * 3 of them, wave w takes tiles w and w + 4
+  const int n16 = 3 * n_tiles;
+  double* Xt0 = (wave < 3 ? Xa + 16 * wave * ULD : Xb);
+  double* Xt1 = Xb + 16 * (wave + 1) * ULD;          // tiles 4, 5 = rows 16.., 32.. of the second tile
+  const bool two = wave + 4 < n16;
+  const bool one = wave < n16;
+  if (one) {   // wave-uniform
+    const double* pa0 = Xt0 + arow * ULD + kq;
+    const double* pa1 = Xt1 + arow * ULD + kq;
+#pragma unroll
+    for (int b = 0; b < 3; ++b) {
+      const double* gb = sL + (16 * b + arow) * LDD + kq;
+      const double* mb = sM + 16 * MLD * b + MLD * arow + kq;
+      double bv[12], av0[12], av1[12];
+#pragma unroll
+      for (int s2 = 0; s2 < 12; ++s2) {
+        if (s2 >= 4 * b + 4) continue;
+        bv[s2] = s2 < 4 * b ? gb[4 * s2] : mb[4 * (s2 - 4 * b)];
+        av0[s2] = pa0[4 * s2];
+        av1[s2] = two ? pa1[4 * s2] : 0.0;
+      }
+      double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int s2 = 0; s2 < 12; ++s2) {
+        if (s2 >= 4 * b + 4) continue;
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[s2], bv[s2], acc0, 0, 0, 0);
+        if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[s2], bv[s2], acc1, 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+      // D layout: col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        Xt0[(kq + 4 * r) * ULD + 16 * b + arow] = acc0[r];
+        if (two) Xt1[(kq + 4 * r) * ULD + 16 * b + arow] = acc1[r];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    }
+  }
+  __syncthreads();
+  VUS_TMARK(4);
+}
+
+__global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
+                                                               int n_update, int k0_prev, double* __restrict__ yv,
+                                                               size_t ystride, int n_rhs) {
   __shared__ double Xi[UT * ULD];
   __shared__ double Xj[UT * ULD];
+  __shared__ double sL[NB * LDD];
+  __shared__ double sM[3 * 16 * MLD];
+  __shared__ double sInv[NB];
+  VUS_TMARK(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if ((int)blockIdx.x >= n_update) {
+    // write-back of the previous panel's rows: tile t of its window
+    const int t = (int)blockIdx.x - n_update;
+    const int pbp = min(PB, n_poses - k0_prev);
+    const int i_first = k0_prev + pbp;
+    const int i_last = min(n_poses - 1, k0_prev + pbp - 1 + band);
+    const int p0 = i_first + t * UTP;
+    stage_and_solve(Sb, band, k0_prev, pbp, i_last, p0, p0, 1, Xi, Xi, sL, sM, sInv);
+    for (int e = tid; e < UT * PB; e += 256) {
+      const int lr = e / PB, kk = e - lr * PB;
+      const int i = p0 + lr / 6, rr = lr % 6;
+      if (i <= i_last && kk < pbp && kk >= max(0, i - band - k0_prev)) {
+        double* b = blk_ptr(Sb, band, i, k0_prev + kk) + 6 * rr;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) b[c] = Xi[lr * ULD + 6 * kk + c];
+      }
+    }
+    return;
+  }
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
   const int i_first = k0 + pb;
   const int i_last = min(n_poses - 1, k0 + pb - 1 + band);
   // tile (ti, tj), tj <= ti, from the linear block index
-  int ti = (int)((sqrt(8.0 * (double)blockIdx.x + 1.0) - 1.0) * 0.5);
+  int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
   while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
   while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
   const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
   const int pi0 = i_first + ti * UTP, pj0 = i_first + tj * UTP;   // first pose of the tile rows / columns
-  // stage X_i and X_j (rows x 48) in LDS; rows past the window or left of the band are zero
-  for (int t = tid; t < 2 * UT * PB; t += 256) {
-    const int which = t / (UT * PB);
-    const int u = t - which * (UT * PB);
-    const int lr = u / PB, kk = u - lr * PB;     // local scalar row, panel pose
-    const int i = (which ? pj0 : pi0) + lr / 6, rr = lr % 6;
-    double* dst = (which ? Xj : Xi) + lr * ULD + 6 * kk;
-    const bool have = i <= i_last && kk < pb && kk >= max(0, i - band - k0);
-    const double* b = have ? blk_ptr(Sb, band, i, k0 + kk) + 6 * rr : nullptr;
-#pragma unroll
-    for (int c = 0; c < 6; ++c) dst[c] = have ? b[c] : 0.0;
-  }
-  __syncthreads();
+  const double* Xjj = (ti == tj) ? Xi : Xj;
   const int arow = lane & 15, kq = lane >> 4;
-  // this wave's 9 MFMA tiles: accumulate X_i X_j^T - A and store the negation, so the old values
-  // enter as the C operand (their loads overlap the LDS reads) instead of a read-modify-write tail
+  // element (row Rr of pose i, column Cc of pose j) lives at rowoff + coloff: the offsets separate
+  long long coloff[UMT];
+  int cj[UMT], ccm[UMT];
+#pragma unroll
+  for (int b = 0; b < UMT; ++b) {
+    const int Cc = 16 * b + arow;
+    cj[b] = pj0 + Cc / 6;
+    ccm[b] = Cc % 6;
+    coloff[b] = -36ll * cj[b] + ccm[b];
+  }
+  // this wave's MFMA tiles: accumulate X_i X_j^T - A and store the negation, so the old values enter
+  // as the C operand (their loads are in flight during the solve) instead of a read-modify-write tail
   double4_t acc[UQ];
   bool ok[UQ][4];
+  long long off[UQ][4];
 #pragma unroll
   for (int q = 0; q < UQ; ++q) {
     const int t = wave + 4 * q;
     const int a = t / UMT, b = t - UMT * a;
-    const int Cc = 16 * b + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int Rr = 16 * a + (lane >> 4) + 4 * r;
-      const int i = pi0 + Rr / 6, j = pj0 + Cc / 6;
-      ok[q][r] = t < UMT * UMT && i <= i_last && j <= i && (j < i || (Cc % 6) <= (Rr % 6));
-      const double* src = ok[q][r] ? blk_ptr(Sb, band, i, j) + 6 * (Rr % 6) + (Cc % 6) : Sb;
-      acc[q][r] = -*src;
+      const int Rr = 16 * a + kq + 4 * r;
+      const int i = pi0 + Rr / 6, rm = Rr % 6;
+      ok[q][r] = t < UMT * UMT && i <= i_last && cj[b] <= i && (cj[b] < i || ccm[b] <= rm);
+      off[q][r] = ok[q][r] ? 36ll * ((long long)i * (band + 2)) + 6 * rm + coloff[b] : 0;
+      acc[q][r] = -Sb[off[q][r]];
     }
   }
+  stage_and_solve(Sb, band, k0, pb, i_last, pi0, pj0, ti == tj ? 1 : 2, Xi, Xj, sL, sM, sInv);
 #pragma unroll
   for (int q = 0; q < UQ; ++q) {
     const int t = wave + 4 * q;
     const int a = t / UMT, b = t - UMT * a;
     if (t >= UMT * UMT || (ti == tj && b > a)) continue;   // strictly upper tiles of a diagonal workgroup
     const double* pa = Xi + (16 * a + arow) * ULD + kq;
-    const double* pbm = Xj + (16 * b + arow) * ULD + kq;
+    const double* pbm = Xjj + (16 * b + arow) * ULD + kq;
 #pragma unroll
     for (int s = 0; s < NB / 4; ++s) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s], pbm[4 * s], acc[q], 0, 0, 0);
   }
+  VUS_TMARK(5);
   // C/D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
 #pragma unroll
   for (int q = 0; q < UQ; ++q) {
     const int t = wave + 4 * q;
     const int a = t / UMT, b = t - UMT * a;
     if (t >= UMT * UMT || (ti == tj && b > a)) continue;
-    const int Cc = 16 * b + (lane & 15);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int Rr = 16 * a + (lane >> 4) + 4 * r;
-      const int i = pi0 + Rr / 6, j = pj0 + Cc / 6;
-      if (ok[q][r]) blk_ptr(Sb, band, i, j)[6 * (Rr % 6) + (Cc % 6)] = -acc[q][r];
-    }
+    for (int r = 0; r < 4; ++r)
+      if (ok[q][r]) Sb[off[q][r]] = -acc[q][r];
   }
+  VUS_TMARK(6);
+#ifdef VUS_TIMING
+  if (threadIdx.x == 0 && blockIdx.x == 37 && k0 == 800)
+    printf("TM %llu %llu %llu %llu %llu %llu\n", g_tm[1] - g_tm[0], g_tm[2] - g_tm[1], g_tm[3] - g_tm[2],
+           g_tm[4] - g_tm[3], g_tm[5] - g_tm[4], g_tm[6] - g_tm[5]);
+#endif
   if (ti == tj && tid < UT) {
     const int i = pi0 + tid / 6;
     if (i <= i_last)
@@ -1000,6 +1155,7 @@ int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, 
   const int n = 6 * n_nodes;
   const size_t ystride = (size_t)n;
   VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+  int k0_prev = -1, tiles_prev = 0;
   for (int k0 = 0; k0 < n_nodes; k0 += PB) {
     chol_panel_kernel<<<1, 256, 0, st>>>(Sband, n_nodes, band, k0, y, ystride, n_rhs, status);
     const int pb = n_nodes - k0 < PB ? n_nodes - k0 : PB;
@@ -1007,11 +1163,14 @@ int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, 
     int i_last = k0 + pb - 1 + band;
     if (i_last > n_nodes - 1) i_last = n_nodes - 1;
     const int rows = i_last - i_first + 1;
-    if (rows > 0) {
-      chol_trsm_kernel<<<cdiv(6ll * rows, TRSM_T), TRSM_T, 0, st>>>(Sband, n_nodes, band, k0);
-      const int tiles = (rows + UTP - 1) / UTP;
-      chol_update_kernel<<<tiles * (tiles + 1) / 2, 256, 0, st>>>(Sband, n_nodes, band, k0, y, ystride, n_rhs);
-    }
+    const int tiles = rows > 0 ? (rows + UTP - 1) / UTP : 0;
+    const int n_update = tiles * (tiles + 1) / 2;
+    // update tiles of this panel + the write-back of the previous panel's solved rows
+    if (n_update + tiles_prev > 0)
+      chol_trsm_update_kernel<<<n_update + tiles_prev, 256, 0, st>>>(Sband, n_nodes, band, k0, n_update, k0_prev, y,
+                                                                   ystride, n_rhs);
+    k0_prev = k0;
+    tiles_prev = tiles;
   }
   const size_t lds = (n_rhs == 1 && n <= BS_LDS_N) ? sizeof(double) * (size_t)n : 0;
   if (lds > 48 * 1024)  // more than the default dynamic-LDS allowance: gfx950 has 160 KiB per workgroup
