@@ -212,7 +212,8 @@ int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lamb
  * value = -(n_ranks-1)*lambda restores a single copy. */
 int vus_ba_add_diag(double* Sband, int n_poses, int band, double value, void* stream);
 
-/* Solve S dp = -gs by block-band Cholesky (Sband is overwritten by its factor); n_poses counts NODES.
+/* Solve S dp = -gs by block-band Cholesky; n_poses counts NODES.  Sband is overwritten by the factor L in
+ * the solver's own layout: the 6x6 blocks left of the 8-node diagonal panels hold their transposes.
  * status[0] = 0 ok, k+1 = non-positive pivot met in scalar column k (dp is then undefined). */
 int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, double* dp,
                       int* status, void* stream);

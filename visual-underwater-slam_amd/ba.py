@@ -213,6 +213,8 @@ class StereoBASolver:
                 self.eval_step(poses, points)
                 sc = self.scal.cpu()                              # one sync per trial
                 status = int(self.status.item())
+                if status < 0:
+                    raise RuntimeError("vus_ba_band_solve: the cooperative back-substitution timed out (status %d)" % status)
                 rep.tries += 1
                 a_lin, a_new = aux.try_lambda(lam) if aux else (0.0, 0.0)
                 if lin0 is None:
@@ -390,6 +392,8 @@ class NavBASolver(StereoBASolver):
                 self.nav_eval_step(poses, vels, bias)
                 sc, nsc = self.scal.cpu(), self.nav_scal.cpu()
                 status = int(self.status.item())
+                if status < 0:
+                    raise RuntimeError("vus_ba_band_solve: the cooperative back-substitution timed out (status %d)" % status)
                 rep.tries += 1
                 if lin0 is None:
                     lin0 = float(sc[0]) + float(nsc[0])

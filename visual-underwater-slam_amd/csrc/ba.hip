@@ -790,13 +790,16 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
     const int i_last = min(n_poses - 1, k0_prev + pbp - 1 + band);
     const int p0 = i_first + t * UTP;
     stage_and_solve(Sb, band, k0_prev, pbp, i_last, p0, p0, 1, Xi, Xi, sL, sM, sInv);
-    for (int e = tid; e < UT * PB; e += 256) {
-      const int lr = e / PB, kk = e - lr * PB;
-      const int i = p0 + lr / 6, rr = lr % 6;
+    // stored TRANSPOSED ([column][row] inside each 6x6 block): the back-substitution, the only reader,
+    // walks these blocks by column
+    for (int e = tid; e < UTP * PB * 6; e += 256) {
+      const int ii = e / (6 * PB), rem = e - 6 * PB * ii;
+      const int kk = rem / 6, c = rem - 6 * kk;
+      const int i = p0 + ii;
       if (i <= i_last && kk < pbp && kk >= max(0, i - band - k0_prev)) {
-        double* b = blk_ptr(Sb, band, i, k0_prev + kk) + 6 * rr;
+        double* b = blk_ptr(Sb, band, i, k0_prev + kk) + 6 * c;
 #pragma unroll
-        for (int c = 0; c < 6; ++c) b[c] = Xi[lr * ULD + 6 * kk + c];
+        for (int r = 0; r < 6; ++r) b[r] = Xi[(6 * ii + r) * ULD + 6 * kk + c];
       }
     }
     return;
@@ -881,75 +884,184 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
   }
 }
 
-// x = L^-T y in place (yv), from the last panel to the first, one workgroup.  Per panel: the 48x48
-// triangular solve runs on wave 0 (lane = row, right-looking, x broadcast with readlane), then all
-// threads subtract the panel's contribution from the rows above it.  y lives in LDS when it fits.
-constexpr int BS_THREADS = 1024;
-constexpr int BS_LDS_N = 12288;
+// x = L^-T y in place (yv), from the last panel to the first.
+//
+// One compute unit cannot stream the factor fast enough (a single CU sustains ~35 GB/s from HBM, the
+// factor of a 2000-pose / band-224 problem is 130 MB), so the sweep is spread over one workgroup per
+// 8-pose row group of the band:
+//   workgroup 0 (the solver) owns the sequential part: per panel p (last to first) it waits until the
+//     contributions to y_p have arrived, solves the 48x48 diagonal block (lane = row, the lane's
+//     pre-scaled column of L in registers, x broadcast with readlane: two dependent instructions per
+//     column), publishes x_p, and computes the contribution of x_p to the panel right above itself;
+//   workgroup g >= 1 waits for x_p, multiplies it with the blocks L(panel p, panel p - g - 1)^T --
+//     transposed on write-back, so an output reads one contiguous 48-byte block row -- and adds the
+//     result to y with f64 atomics.  Its operands are loaded one panel ahead of the x it waits for.
+// Flags (agent-scope release/acquire): F[0] = panels solved, F[1] = abort, F[2 + g] = panels done by
+// workgroup g.  Every wait is bounded: a wait that expires raises the abort flag, all loops drain and
+// status = -1.  Only every 8th block of the grid works, which places all of them on one XCD (one L2).
 constexpr int BS_MAX_RHS = 8;
-__global__ __launch_bounds__(BS_THREADS) void chol_backsolve_kernel(const double* __restrict__ Sb, int n_poses,
-                                                                    int band, double* __restrict__ yv, size_t ystride,
-                                                                    int n_rhs) {
-  extern __shared__ double s_y[];
-  __shared__ double s_L[NB * LDD];
-  __shared__ double s_x[BS_MAX_RHS][NB];
-  const int tid = threadIdx.x;
-  const int n = 6 * n_poses;
-  const bool in_lds = n_rhs == 1 && n <= BS_LDS_N;   // single right-hand side: keep it in LDS
-  double* y = in_lds ? s_y : yv;
-  const size_t ys = in_lds ? 0 : ystride;
-  if (in_lds)
-    for (int t = tid; t < n; t += BS_THREADS) s_y[t] = yv[t];
-  const int n_panels = (n_poses + PB - 1) / PB;
-  for (int p = n_panels - 1; p >= 0; --p) {
-    const int k0 = p * PB;
-    const int pb = min(PB, n_poses - k0), nb = 6 * pb;
-    for (int t = tid; t < NB * NB; t += BS_THREADS) {   // the panel's lower-triangular diagonal block
-      const int R = t / NB, C = t - R * NB;
-      const int ii = R / 6, kk = C / 6;
-      double v = (R == C) ? 1.0 : 0.0;
-      if (R < nb && C <= R && ii - kk <= band) v = blk_ptr(Sb, band, k0 + ii, k0 + kk)[6 * (R % 6) + (C % 6)];
-      s_L[R * LDD + C] = (R == C) ? 1.0 / v : v;   // the diagonal is stored inverted
-    }
-    __syncthreads();
-    if (tid < 64 * n_rhs) {   // wave q solves right-hand side q
-      const int q = tid >> 6, lane = tid & 63;
-      double* yq = y + (size_t)q * ys;
-      double yr = lane < nb ? yq[6 * k0 + lane] : 0.0;
-      for (int c = nb - 1; c >= 0; --c) {     // L^T x = y: x_c = y_c / L_cc, then y_r -= L_cr x_c for r < c
-        const double xc = bcast_lane(yr, c) * s_L[c * LDD + c];
-        if (lane == c) yr = xc;
-        else if (lane < c) yr -= s_L[c * LDD + lane] * xc;
-      }
-      if (lane < nb) { yq[6 * k0 + lane] = yr; s_x[q][lane] = yr; }
-    }
-    __syncthreads();
-    const int i0 = max(0, k0 - band);   // rows above the panel that hold a block in some panel row
-    for (int t = tid; t < 6 * (k0 - i0); t += BS_THREADS) {
-      const int i = i0 + t / 6, c = t % 6;
-      double acc[BS_MAX_RHS];
-#pragma unroll
-      for (int q = 0; q < BS_MAX_RHS; ++q) acc[q] = 0.0;
-      for (int kk = 0; kk < pb; ++kk) {
-        if (k0 + kk - i > band) break;
-        const double* Lki = blk_ptr(Sb, band, k0 + kk, i) + c;
-        double l[6];
-#pragma unroll
-        for (int r = 0; r < 6; ++r) l[r] = Lki[6 * r];
-#pragma unroll
-        for (int q = 0; q < BS_MAX_RHS; ++q)
-          if (q < n_rhs)
-#pragma unroll
-            for (int r = 0; r < 6; ++r) acc[q] += l[r] * s_x[q][6 * kk + r];
-      }
-#pragma unroll
-      for (int q = 0; q < BS_MAX_RHS; ++q)
-        if (q < n_rhs) y[(size_t)q * ys + 6 * i + c] -= acc[q];
-    }
-    __syncthreads();
+constexpr int CB_THREADS = 512;          // 8 solver waves at most; threads < 8 * 48 = (panel row kk, output 6a + c)
+constexpr int CB_SPIN_LIMIT = 1 << 22;
+
+// Data that crosses workgroups (x, y, the flags) is only touched with agent-scope atomics, which are
+// performed at the coherence point themselves; ordering is program order + s_waitcnt vmcnt(0) before a
+// flag is raised.  No __threadfence(): its L2 write-back / invalidate costs ~10 us per panel here.
+__device__ __forceinline__ int cb_load(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void cb_drain() {   // every vector-memory operation of this wave has completed
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+  __builtin_amdgcn_s_waitcnt(0);
+}
+
+// true once *f >= need; false after an abort (raised here when the wait expires)
+__device__ __forceinline__ bool cb_wait(const int* f, int need, int* abort_flag) {
+  for (int it = 0; it < CB_SPIN_LIMIT; ++it) {
+    if (cb_load(f) >= need) return true;
+    if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
+    __builtin_amdgcn_s_sleep(1);
   }
-  if (in_lds)
-    for (int t = tid; t < n; t += BS_THREADS) yv[t] = s_y[t];
+  __hip_atomic_store(abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return false;
+}
+
+// column `lane` of the diagonal block, pre-scaled: Lp[c] = L[c][lane] / L[lane][lane] for c > lane, else 0
+__device__ __forceinline__ void cb_load_diag(const double* __restrict__ Sb, int band, int k0, int nb, int lane,
+                                             double (&Lp)[NB], double& dinv) {
+  const int lr6 = lane / 6, lrm = lane - 6 * lr6;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    const bool have = c < nb && lane < c && c / 6 - lr6 <= band;
+    const double* src = have ? blk_ptr(Sb, band, k0 + c / 6, k0 + lr6) + 6 * (c % 6) + lrm : Sb;
+    Lp[c] = *src;
+    if (!have) Lp[c] = 0.0;
+  }
+  const double dg = lane < nb ? blk_ptr(Sb, band, k0 + lr6, k0 + lr6)[7 * lrm] : 1.0;
+  dinv = 1.0 / dg;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) Lp[c] *= dinv;
+}
+
+__global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(const double* __restrict__ Sb, int n_poses,
+                                                                    int band, double* yv, size_t ystride, int n_rhs,
+                                                                    int n_groups, int* F, int* __restrict__ status) {
+  if (blockIdx.x & 7) return;
+  const int g = blockIdx.x >> 3;
+  __shared__ double s_x[BS_MAX_RHS][NB];
+  __shared__ double s_part[BS_MAX_RHS][PB][NB];
+  __shared__ double s_own[BS_MAX_RHS][NB];
+  __shared__ int s_go;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int NP = (n_poses + PB - 1) / PB;
+  const int kk = tid / NB, oc = tid - NB * kk;    // update task: panel row kk, output oc = 6a + c
+  const int a = oc / 6, c = oc - 6 * a;
+  int* abort_flag = F + 1;
+  // this thread's block row for panel p: row c of the transposed block (8p + kk, 8p - 8g - 8 + a)
+  d2a_t l[3];
+  bool have;
+#define CB_LOAD_ROWS(P)                                                                                \
+  {                                                                                                    \
+    const int k0_ = PB * (P), i_ = k0_ - PB * g - PB + a;                                              \
+    have = kk < PB && i_ >= 0 && k0_ + kk < n_poses && k0_ + kk - i_ <= band;                                     \
+    const d2a_t* src_ = reinterpret_cast<const d2a_t*>(have ? blk_ptr(Sb, band, k0_ + kk, i_) + 6 * c : Sb); \
+    l[0] = src_[0]; l[1] = src_[1]; l[2] = src_[2];                                                    \
+  }
+#define CB_PARTIAL_DOTS()                                                                              \
+  for (int q = 0; q < (kk < PB ? n_rhs : 0); ++q) {                                                                    \
+    const double* xq = &s_x[q][6 * kk];                                                                \
+    const double d = l[0].x * xq[0] + l[0].y * xq[1] + l[1].x * xq[2] + l[1].y * xq[3] + l[2].x * xq[4] + l[2].y * xq[5]; \
+    s_part[q][kk][oc] = have ? d : 0.0;                                                                \
+  }
+  CB_LOAD_ROWS(NP - 1);
+  if (g == 0) {
+    // ---- solver ----
+    double Lp[NB];
+    double dinv = 1.0;
+    if (wave < n_rhs) {
+      const int k0 = PB * (NP - 1);
+      cb_load_diag(Sb, band, k0, 6 * min(PB, n_poses - k0), lane, Lp, dinv);
+    }
+    for (int s = 0; s < NP; ++s) {
+      const int p = NP - 1 - s, k0 = PB * p;
+      const int nb = 6 * min(PB, n_poses - k0);
+      if (wave == 0) {   // every workgroup that adds to y_p must have finished the panel it comes from
+        bool ok = true;
+        for (int g0 = 1; g0 < n_groups && ok; g0 += 64) {
+          const int gg = g0 + lane;
+          if (gg < n_groups && s - gg > 0) ok = cb_wait(F + 2 + gg, s - gg, abort_flag);
+          ok = __all(ok);
+        }
+        if (lane == 0) s_go = ok;
+      }
+      __syncthreads();
+      if (!s_go) break;
+      if (wave < n_rhs) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        double* yq = yv + (size_t)wave * ystride;
+        double yr = lane < nb ? __hip_atomic_load(&yq[6 * k0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        if (s > 0 && lane < NB) yr -= s_own[wave][lane];
+        double z = yr * dinv;           // z_r = y_r / L_rr;  x_c = z_c once every column > c is applied
+#pragma unroll
+        for (int cc = NB - 1; cc >= 0; --cc)
+          if (cc < nb) z -= Lp[cc] * bcast_lane(z, cc);
+        if (lane < nb) {
+          __hip_atomic_store(&yq[6 * k0 + lane], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          s_x[wave][lane] = z;
+        } else if (lane < NB) {
+          s_x[wave][lane] = 0.0;
+        }
+        cb_drain();
+      }
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(F, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (p > 0) {   // contribution of x_p to the panel right above (kept in LDS, subtracted at the next step)
+        CB_PARTIAL_DOTS();
+        __syncthreads();
+        if (tid < NB * n_rhs) {
+          const int q = tid / NB, r = tid - NB * q;
+          double sum = 0.0;
+#pragma unroll
+          for (int k2 = 0; k2 < PB; ++k2) sum += s_part[q][k2][r];
+          s_own[q][r] = sum;
+        }
+        if (wave < n_rhs) cb_load_diag(Sb, band, k0 - PB, NB, lane, Lp, dinv);
+        CB_LOAD_ROWS(p - 1);
+      }
+      __syncthreads();
+    }
+  } else {
+    // ---- row group g: panels NP-1 .. g+1 contribute to panels NP-g-2 .. 0 ----
+    for (int s = 0; s < NP - g - 1; ++s) {
+      const int p = NP - 1 - s, k0 = PB * p;
+      const int nb = 6 * min(PB, n_poses - k0);
+      if (tid == 0) s_go = cb_wait(F, s + 1, abort_flag);
+      __syncthreads();
+      if (!s_go) break;
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      if (tid < NB * n_rhs) {
+        const int q = tid / NB, r = tid - NB * q;
+        s_x[q][r] = r < nb ? __hip_atomic_load(&yv[(size_t)q * ystride + 6 * k0 + r], __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT)
+                           : 0.0;
+      }
+      __syncthreads();
+      CB_PARTIAL_DOTS();
+      __syncthreads();
+      if (tid < NB * n_rhs) {
+        const int q = tid / NB, r = tid - NB * q;
+        double sum = 0.0;
+#pragma unroll
+        for (int k2 = 0; k2 < PB; ++k2) sum += s_part[q][k2][r];
+        const int row = 6 * (k0 - PB * g - PB) + r;    // >= 0: this group stops at panel g + 1
+        __hip_atomic_fetch_add(&yv[(size_t)q * ystride + row], -sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      cb_drain();
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(F + 2 + g, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (s + 1 < NP - g - 1) CB_LOAD_ROWS(p - 1);
+    }
+  }
+#undef CB_LOAD_ROWS
+#undef CB_PARTIAL_DOTS
+  if (tid == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) status[0] = -1;
 }
 
 __global__ void add_diag_kernel(double* __restrict__ Sband, int n_poses, int band, double value) {
@@ -1151,9 +1263,16 @@ extern "C" int vus_ba_add_diag(double* Sband, int n_poses, int band, double valu
 }
 
 namespace {
+// band == 0 has no spare slot in Sband: the solver runs alone and only touches F[0], F[1]; a process-wide
+// 16-int device buffer serves (allocated once).
+int* flags_fallback(hipStream_t) {
+  static int* buf = nullptr;
+  if (!buf && hipMalloc(&buf, 16 * sizeof(int)) != hipSuccess) buf = nullptr;
+  return buf;
+}
+
 int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, int* status, hipStream_t st) {
-  const int n = 6 * n_nodes;
-  const size_t ystride = (size_t)n;
+  const size_t ystride = 6 * (size_t)n_nodes;
   VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
   int k0_prev = -1, tiles_prev = 0;
   for (int k0 = 0; k0 < n_nodes; k0 += PB) {
@@ -1172,11 +1291,14 @@ int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, 
     k0_prev = k0;
     tiles_prev = tiles;
   }
-  const size_t lds = (n_rhs == 1 && n <= BS_LDS_N) ? sizeof(double) * (size_t)n : 0;
-  if (lds > 48 * 1024)  // more than the default dynamic-LDS allowance: gfx950 has 160 KiB per workgroup
-    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_backsolve_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-  chol_backsolve_kernel<<<1, BS_THREADS, lds, st>>>(Sband, n_nodes, band, y, ystride, n_rhs);
+  // flags of the cooperative sweep live in the unused slots of block row 0 (blocks (0, k < 0))
+  const int n_groups = band > 0 ? (band + PB - 1) / PB : 1;
+  int* F = band > 0 ? reinterpret_cast<int*>(Sband + 36) : flags_fallback(st);
+  VUS_REQUIRE(F != nullptr, "no scratch for the solver flags");
+  VUS_REQUIRE(band == 0 || 2 + n_groups <= 72 * band, "band=%d: too many row groups for the flag area", band);
+  VUS_CHECK_HIP(hipMemsetAsync(F, 0, sizeof(int) * (size_t)(2 + n_groups), st));
+  chol_backsolve_kernel<<<8 * n_groups, CB_THREADS, 0, st>>>(Sband, n_nodes, band, y, ystride, n_rhs, n_groups, F,
+                                                             status);
   VUS_CHECK_LAUNCH("ba_band_solve");
   return VUS_OK;
 }
