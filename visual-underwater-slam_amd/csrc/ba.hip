@@ -471,17 +471,19 @@ __device__ __forceinline__ double bcast_lane(double v, int src_lane) {   // src_
   return __hiloint2double(hi, lo);
 }
 
+// v_rsq_f64 delivers ~24 bits (measured 5.2e-8, tools/ubench/rsq_prec.hip); one third-order step
+// r (1 + h/2 + 3h^2/8), h = 1 - d r^2, brings it to 1 ulp in five dependent operations.
 __device__ __forceinline__ double rsqrt_newton(double d) {
-  double r = __builtin_amdgcn_rsq(d);
-  r = r * (1.5 - 0.5 * d * r * r);
-  r = r * (1.5 - 0.5 * d * r * r);
-  return r;
+  const double r = __builtin_amdgcn_rsq(d);
+  const double h = __builtin_fma(-(d * r), r, 1.0);
+  const double p = __builtin_fma(0.375, h, 0.5);
+  return __builtin_fma(r * h, p, r);
 }
 
 // Four waves, lane R of every wave = row R of the 48x48 block (rows nb.. = the right-hand sides riding
 // along); wave w keeps the 6-column blocks kb = w and w + 4 of its rows in registers.  Block step s: the
 // owner wave pulls the 6x6 diagonal block into SGPRs (readlane), factors it in registers, solves its rows
-// against it and publishes them through a double-buffered LDS panel; one barrier per block step, and the
+// against it and publishes them through a ring of three LDS panels; one barrier per block step, and the
 // owner of block s+1 updates that block first and factors it while the other waves finish step s.
 __device__ __forceinline__ void panel_update(double (&blk)[6], const double (&xr)[6], const double* __restrict__ xs) {
 #pragma unroll
@@ -493,11 +495,23 @@ __device__ __forceinline__ void panel_update(double (&blk)[6], const double (&xr
   }
 }
 
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
-                                                         double* __restrict__ yv, size_t ystride, int n_rhs,
-                                                         int* __restrict__ status) {
-  __shared__ __attribute__((aligned(16))) double s_x[2][64 * 6];
-  __shared__ int s_bad;
+#ifdef VUS_TIMING
+#define VUS_PT(n) const unsigned long long pt##n = __builtin_amdgcn_s_memtime()
+#define VUS_PP() printf("PF %llu %llu %llu\n", pt1 - pt0, pt2 - pt1, pt3 - pt2)
+#else
+#define VUS_PT(n)
+#define VUS_PP()
+#endif
+// COHERENT: the inputs were written by this workgroup a moment ago (fused launch): read them past the L1.
+template <bool COHERENT>
+__device__ __forceinline__ double panel_ld(const double* p) {
+  return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+
+template <bool COHERENT>
+__device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, int k0, double* yv, size_t ystride,
+                                             int n_rhs, int* __restrict__ status, double (*s_x)[64 * 6],
+                                             int& s_bad) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
@@ -515,24 +529,26 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb
     if (R < nb && kb <= ii && ii - kb <= band) {
       const double* src = blk_ptr(Sb, band, k0 + ii, k0 + kb) + 6 * rr;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) row[j][c] = src[c];
+      for (int c = 0; c < 6; ++c) row[j][c] = panel_ld<COHERENT>(src + c);
     }
     if (is_rhs && kb < pb) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) row[j][c] = yrow[6 * kb + c];
+      for (int c = 0; c < 6; ++c) row[j][c] = panel_ld<COHERENT>(yrow + 6 * kb + c);
     }
   }
+  VUS_PT(0);
   __syncthreads();
+  VUS_PT(1);
 #pragma unroll
   for (int s = 0; s < PB; ++s) {
     if (s < pb) {   // uniform
+      double xp[6];
       if (wave == (s & 3)) {
         double (&a)[6] = row[s >> 2];
-        double xp[6];
         if (s > 0) {   // look-ahead: bring this block up to date with step s-1 before factoring it
 #pragma unroll
-          for (int k = 0; k < 6; ++k) xp[k] = s_x[(s - 1) & 1][6 * lane + k];
-          panel_update(a, xp, &s_x[(s - 1) & 1][36 * s]);
+          for (int k = 0; k < 6; ++k) xp[k] = s_x[(s - 1) % 3][6 * lane + k];
+          panel_update(a, xp, &s_x[(s - 1) % 3][36 * s]);
         }
         double D[6][6], inv[6];
 #pragma unroll
@@ -564,26 +580,30 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb
           a[c] = acc * inv[c];
         }
 #pragma unroll
-        for (int k = 0; k < 6; ++k) s_x[s & 1][6 * lane + k] = a[k];
-        // the step s-1 update of this wave's other block was deferred behind the factorisation
-        if (s > 0 && s < 4 && s + 4 < pb) panel_update(row[1], xp, &s_x[(s - 1) & 1][36 * (s + 4)]);
+        for (int k = 0; k < 6; ++k) s_x[s % 3][6 * lane + k] = a[k];
       }
       __syncthreads();
+      // the step s-1 update of the owner's other block was deferred behind the factorisation and the
+      // barrier (the ring of three buffers keeps step s-1 readable until the barrier of step s+1)
+      if (wave == (s & 3) && s > 0 && s < 4 && s + 4 < pb) panel_update(row[1], xp, &s_x[(s - 1) % 3][36 * (s + 4)]);
       {
         double xr[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) xr[k] = s_x[s & 1][6 * lane + k];
+        for (int k = 0; k < 6; ++k) xr[k] = s_x[s % 3][6 * lane + k];
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int kb = wave + 4 * j;
           // block s+1 is updated by its owner at the top of the next step
           if (4 * j + 3 > s && kb > s + 1 && kb < pb && !(wave == ((s + 1) & 3) && s + 1 < pb))
-            panel_update(row[j], xr, &s_x[s & 1][36 * kb]);
+            panel_update(row[j], xr, &s_x[s % 3][36 * kb]);
         }
       }
     }
   }
+  VUS_PT(2);
   __syncthreads();
+  VUS_PT(3);
+  if (COHERENT && threadIdx.x == 0 && k0 == 808) VUS_PP();
   if (threadIdx.x == 0 && s_bad != 0x7FFFFFFF && status[0] == 0) status[0] = s_bad;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -598,6 +618,14 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb
       for (int c = 0; c < 6; ++c) yrow[6 * kb + c] = row[j][c];
     }
   }
+}
+
+__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
+                                                         double* __restrict__ yv, size_t ystride, int n_rhs,
+                                                         int* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) double s_x[3][64 * 6];
+  __shared__ int s_bad;
+  panel_factor<false>(Sb, n_poses, band, k0, yv, ystride, n_rhs, status, s_x, s_bad);
 }
 
 // Rows below the panel, fused with the trailing update.  X = A_rows,panel * L_D^-T is what a TRSM
@@ -621,7 +649,7 @@ constexpr int MLD = 17;           // LDS row stride of the 16x16 inverse blocks
 
 #ifdef VUS_TIMING
 __device__ unsigned long long g_tm[8];
-#define VUS_TMARK(n) do { if (threadIdx.x == 0 && blockIdx.x == 37) g_tm[n] = __builtin_amdgcn_s_memtime(); } while (0)
+#define VUS_TMARK(n) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_tm[n] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define VUS_TMARK(n)
 #endif
@@ -694,19 +722,47 @@ __device__ __forceinline__ void stage_and_solve(const double* __restrict__ Sb, i
   }
   __syncthreads();
   VUS_TMARK(1);
-  if (tid < NB) {   // column n of M_b = (16x16 diagonal block)^-1 by forward substitution (rows past nb: identity)
-    const int b = tid >> 4, n = tid & 15;
-    const double* Ld = sL + (16 * b) * LDD + 16 * b;
-    double m[16];
+  // M_b = (16x16 diagonal block b)^-1 from its 8x8 quadrants:  [A 0; C B]^-1 = [A^-1 0; -B^-1 C A^-1  B^-1]
+  if (tid < NB) {   // column n of the inverse of 8x8 diagonal block h by forward substitution (rows past nb: identity)
+    const int h = tid >> 3, n = tid & 7;
+    const double* Ld = sL + (8 * h) * LDD + 8 * h;
+    double m[8];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
+    for (int r = 0; r < 8; ++r) {
       double acc = (r == n) ? 1.0 : 0.0;
 #pragma unroll
       for (int k = 0; k < r; ++k) acc -= Ld[r * LDD + k] * m[k];
-      m[r] = acc * sInv[16 * b + r];
+      m[r] = acc * sInv[8 * h + r];
     }
+    double* Mq = sM + 16 * MLD * (h >> 1) + (8 * MLD + 8) * (h & 1);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sM[16 * MLD * b + MLD * r + n] = m[r];   // row-major [r][n]
+    for (int r = 0; r < 8; ++r) Mq[MLD * r + n] = m[r];
+    if (h & 1) {   // upper-right quadrant of M_b
+#pragma unroll
+      for (int r = 0; r < 8; ++r) sM[16 * MLD * (h >> 1) + MLD * r + 8 + n] = 0.0;
+    }
+  }
+  __syncthreads();
+  {
+    const int b3 = tid >> 6, r = (tid >> 3) & 7, cq = tid & 7;   // threads < 192: element (r, cq) of quadrant C of block b3
+    const bool act = tid < 192;
+    double* Mb = sM + 16 * MLD * (act ? b3 : 0);
+    double t = 0.0;
+    if (act) {   // T = C A^-1
+      const double* Lc = sL + (16 * b3 + 8 + r) * LDD + 16 * b3;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += Lc[k] * Mb[MLD * k + cq];
+      Mb[MLD * (8 + r) + cq] = t;     // parked in the quadrant it will leave
+    }
+    __syncthreads();
+    if (act) {   // -B^-1 T
+      double u = 0.0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u -= Mb[MLD * (8 + r) + 8 + k] * Mb[MLD * (8 + k) + cq];
+      t = u;
+    }
+    __syncthreads();
+    if (act) Mb[MLD * (8 + r) + cq] = t;
   }
   __syncthreads();
   VUS_TMARK(2);
@@ -774,12 +830,13 @@ __device__ __forceinline__ void stage_and_solve(const double* __restrict__ Sb, i
 
 __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
                                                                int n_update, int k0_prev, double* __restrict__ yv,
-                                                               size_t ystride, int n_rhs) {
-  __shared__ double Xi[UT * ULD];
+                                                               size_t ystride, int n_rhs, int* __restrict__ status) {
+  __shared__ __attribute__((aligned(16))) double Xi[UT * ULD];
   __shared__ double Xj[UT * ULD];
   __shared__ double sL[NB * LDD];
   __shared__ double sM[3 * 16 * MLD];
   __shared__ double sInv[NB];
+  __shared__ int s_bad;
   VUS_TMARK(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if ((int)blockIdx.x >= n_update) {
@@ -844,6 +901,11 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
       acc[q][r] = -Sb[off[q][r]];
     }
   }
+  if (ti == tj)   // the panel's solved right-hand sides, for the y update below (Xj is unused by a diagonal tile)
+    for (int e = tid; e < NB * n_rhs; e += 256) {
+      const int q = e / NB, c = e - NB * q;
+      Xj[e] = c < nb ? yv[(size_t)q * ystride + 6 * (size_t)k0 + c] : 0.0;
+    }
   stage_and_solve(Sb, band, k0, pb, i_last, pi0, pj0, ti == tj ? 1 : 2, Xi, Xj, sL, sM, sInv);
 #pragma unroll
   for (int q = 0; q < UQ; ++q) {
@@ -867,20 +929,33 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
       if (ok[q][r]) Sb[off[q][r]] = -acc[q][r];
   }
   VUS_TMARK(6);
-#ifdef VUS_TIMING
-  if (threadIdx.x == 0 && blockIdx.x == 37 && k0 == 800)
-    printf("TM %llu %llu %llu %llu %llu %llu\n", g_tm[1] - g_tm[0], g_tm[2] - g_tm[1], g_tm[3] - g_tm[2],
-           g_tm[4] - g_tm[3], g_tm[5] - g_tm[4], g_tm[6] - g_tm[5]);
-#endif
   if (ti == tj && tid < UT) {
     const int i = pi0 + tid / 6;
     if (i <= i_last)
       for (int q = 0; q < n_rhs; ++q) {
         double* yq = yv + (size_t)q * ystride;
         double acc = 0.0;
-        for (int c = 0; c < nb; ++c) acc += Xi[tid * ULD + c] * yq[6 * (size_t)k0 + c];
+#pragma unroll 8
+        for (int c = 0; c < NB; ++c) acc += Xi[tid * ULD + c] * Xj[NB * q + c];
         yq[6 * (size_t)i + (tid % 6)] -= acc;
       }
+  }
+  VUS_TMARK(7);
+  if (blockIdx.x == 0) {
+    // Tile (0,0) is the next panel's diagonal block, complete once this workgroup has stored it: factor it
+    // here instead of in a launch of its own (the other ~400 workgroups of this launch take as long anyway).
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);     // this wave's stores have reached the L2
+    __syncthreads();                   // ... and so have the other waves'; the X tiles in LDS are dead
+    panel_factor<true>(Sb, n_poses, band, i_first, yv, ystride, n_rhs, status,
+                       reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad);
+#ifdef VUS_TIMING
+    if (threadIdx.x == 0 && k0 == 800) {
+      const unsigned long long t8 = __builtin_amdgcn_s_memtime();
+      printf("TM %llu %llu %llu %llu %llu %llu %llu %llu\n", g_tm[1] - g_tm[0], g_tm[2] - g_tm[1], g_tm[3] - g_tm[2],
+             g_tm[4] - g_tm[3], g_tm[5] - g_tm[4], g_tm[6] - g_tm[5], g_tm[7] - g_tm[6], t8 - g_tm[7]);
+    }
+#endif
   }
 }
 
@@ -1276,7 +1351,8 @@ int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, 
   VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
   int k0_prev = -1, tiles_prev = 0;
   for (int k0 = 0; k0 < n_nodes; k0 += PB) {
-    chol_panel_kernel<<<1, 256, 0, st>>>(Sband, n_nodes, band, k0, y, ystride, n_rhs, status);
+    // panel 0 has a launch of its own; panel p + 1 is factored by tile (0,0) of panel p's update launch
+    if (k0 == 0) chol_panel_kernel<<<1, 256, 0, st>>>(Sband, n_nodes, band, k0, y, ystride, n_rhs, status);
     const int pb = n_nodes - k0 < PB ? n_nodes - k0 : PB;
     const int i_first = k0 + pb;
     int i_last = k0 + pb - 1 + band;
@@ -1287,7 +1363,7 @@ int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, 
     // update tiles of this panel + the write-back of the previous panel's solved rows
     if (n_update + tiles_prev > 0)
       chol_trsm_update_kernel<<<n_update + tiles_prev, 256, 0, st>>>(Sband, n_nodes, band, k0, n_update, k0_prev, y,
-                                                                   ystride, n_rhs);
+                                                                   ystride, n_rhs, status);
     k0_prev = k0;
     tiles_prev = tiles;
   }
