@@ -382,6 +382,14 @@ __global__ void schur_init_kernel(int n_poses, int band, int ps, double lambda, 
 
 // One wave per non-zero block (i,k): S_ik -= sum_pairs Y_a W_b^T.
 // 60 lanes = 5 pair slices x 12 strips (row r, three columns); slices are summed in a fixed order.
+// lane L receives the value of lane L - n of its 16-lane row (0 for the first n lanes): DPP row_shr:n
+template <int CTRL>
+__device__ __forceinline__ double dpp_shr_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+
 __global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, int ps, const double* __restrict__ W,
                                                            const double* __restrict__ Y,
                                                            double* __restrict__ Sband) {
@@ -390,36 +398,51 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, i
   if (q >= S.n_blocks) return;
   const int i = S.blk_i[q], k = S.blk_k[q];
   const int p0 = S.blk_ptr[q], p1 = S.blk_ptr[q + 1];
-  const int sl = lane / 12, within = lane - 12 * sl;
-  const int r = within >> 1, ch = within & 1;
-  double acc0 = 0, acc1 = 0, acc2 = 0;
-  if (sl < 5) {
-    typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte loads from 8-byte aligned rows
-    for (int p = p0 + sl; p < p1; p += 5) {
-      const double* Ya = Y + 18 * (size_t)S.pair_a[p] + 3 * r;
-      const double* Wb = W + 18 * (size_t)S.pair_b[p] + 9 * ch;
-      const d2_t y01 = *reinterpret_cast<const d2_t*>(Ya);
-      const double y2 = Ya[2];
-      const d2_t w01 = *reinterpret_cast<const d2_t*>(Wb), w23 = *reinterpret_cast<const d2_t*>(Wb + 2),
-                 w45 = *reinterpret_cast<const d2_t*>(Wb + 4), w67 = *reinterpret_cast<const d2_t*>(Wb + 6);
-      const double w8 = Wb[8];
-      acc0 += y01.x * w01.x + y01.y * w01.y + y2 * w23.x;
-      acc1 += y01.x * w23.y + y01.y * w45.x + y2 * w45.y;
-      acc2 += y01.x * w67.x + y01.y * w67.y + y2 * w8;
-    }
-  }
-  double t0 = 0, t1 = 0, t2 = 0;
+  // Four lanes per pair: lane (rh, ch) loads rows 3rh..3rh+2 of Y_a and 3ch..3ch+2 of W_b (9 contiguous
+  // doubles each) and accumulates the 3x3 sub-block -- 576 B requested from the L1 per pair instead of
+  // 1152 B with 12 lanes per pair (the kernel is bound by L1 request bandwidth, not by HBM or latency).
+  const int sl = lane >> 2, rh = (lane >> 1) & 1, ch = lane & 1;
+  typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte loads from 8-byte aligned rows
+  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int p = p0 + sl; p < p1; p += 16) {
+    const double* Ya = Y + 18 * (size_t)S.pair_a[p] + 9 * rh;
+    const double* Wb = W + 18 * (size_t)S.pair_b[p] + 9 * ch;
+    double y[10], w[10];
 #pragma unroll
-  for (int s = 0; s < 5; ++s) {
-    t0 += __shfl(acc0, within + 12 * s);
-    t1 += __shfl(acc1, within + 12 * s);
-    t2 += __shfl(acc2, within + 12 * s);
+    for (int h = 0; h < 4; ++h) {
+      const d2_t yv = *reinterpret_cast<const d2_t*>(Ya + 2 * h), wv = *reinterpret_cast<const d2_t*>(Wb + 2 * h);
+      y[2 * h] = yv.x; y[2 * h + 1] = yv.y;
+      w[2 * h] = wv.x; w[2 * h + 1] = wv.y;
+    }
+    y[8] = Ya[8];
+    w[8] = Wb[8];
+#pragma unroll
+    for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+      for (int b2 = 0; b2 < 3; ++b2)
+        acc[a2][b2] += y[3 * a2] * w[3 * b2] + y[3 * a2 + 1] * w[3 * b2 + 1] + y[3 * a2 + 2] * w[3 * b2 + 2];
   }
-  if (lane < 12) {
-    double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k)) + 6 * r + 3 * ch;
-    blk[0] -= t0;
-    blk[1] -= t1;
-    blk[2] -= t2;
+  // sum over the 16 pair slots: inside a 16-lane row with DPP shifts (lanes 12..15 end up with the row
+  // totals of the four (rh, ch) residues), across the four rows through a wave-private LDS patch
+  __shared__ double s_red[4][4][4][9];   // [wave][row][residue][value]
+  const int wv = threadIdx.x >> 6, rowi = (lane >> 4) & 3;
+#pragma unroll
+  for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+    for (int b2 = 0; b2 < 3; ++b2) {
+      double v = acc[a2][b2];
+      v += dpp_shr_f64<0x114>(v);   // row_shr:4
+      v += dpp_shr_f64<0x118>(v);   // row_shr:8
+      if ((lane & 15) >= 12) s_red[wv][rowi][lane & 3][3 * a2 + b2] = v;
+    }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
+  if (lane < 36) {
+    const int res = lane / 9, e = lane - 9 * res;     // residue (rh, ch) = (res >> 1, res & 1), element (a2, b2)
+    const double t = s_red[wv][0][res][e] + s_red[wv][1][res][e] + s_red[wv][2][res][e] + s_red[wv][3][res][e];
+    const int a2 = e / 3, b2 = e - 3 * a2;
+    double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k));
+    blk[6 * (3 * (res >> 1) + a2) + 3 * (res & 1) + b2] -= t;
   }
 }
 
