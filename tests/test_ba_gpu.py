@@ -103,7 +103,10 @@ def test_band_solve_random_spd_bands(gpu, oracle):
     """Random SPD block-band systems, including band 0, band >= n, and n not a multiple of the panel."""
     from visual_underwater_slam_amd import _lib
     rng = np.random.default_rng(0)
-    for nP, B in [(1, 0), (5, 0), (9, 2), (23, 7), (17, 16), (40, 11)]:
+    # the larger cases exercise several panels, several cooperating row groups of the back-substitution
+    # (groups = ceil(B / 8)), more groups than panels, and bands that are not multiples of the panel
+    for nP, B in [(1, 0), (5, 0), (9, 2), (23, 7), (17, 16), (40, 11), (33, 9), (97, 8), (64, 63), (131, 37),
+                  (200, 90), (260, 17)]:
         n = 6 * nP
         A = np.zeros((n, n))
         for i in range(nP):

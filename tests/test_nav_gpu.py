@@ -33,7 +33,7 @@ def setup(oracle, n_kf, n_lm, obs, zero_velocity_prior=True):
 def test_band_solve_multi_rhs(gpu, oracle):
     from visual_underwater_slam_amd import _lib
     rng = np.random.default_rng(0)
-    for nP, B, nr in [(9, 2, 7), (23, 7, 3), (40, 11, 8), (5, 0, 2)]:
+    for nP, B, nr in [(9, 2, 7), (23, 7, 3), (40, 11, 8), (5, 0, 2), (131, 37, 7), (90, 50, 8)]:
         n = 6 * nP
         A = np.zeros((n, n))
         for i in range(nP):
