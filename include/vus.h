@@ -77,6 +77,32 @@ int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_img, int H,
                       const uint32_t* kp_keys, const int* kp_count, int max_kp,
                       uint64_t* desc_out, uint8_t* angle_out, void* stream);
 
+/* ---- optional ORB scale pyramid (ImageProcessorParams.n_levels > 1; Rublee et al. 2011, sec. 6.1:
+ * 8 levels, scale 1.2).  Level l is resized from level l-1; detection, top-K (per-level quota) and
+ * description run on every level with the calls above (H, W, pitch of that level); the per-level
+ * keypoints are then appended, level-major, into one list per image that the matchers consume.
+ *
+ * vus_resize_bilinear: bilinear down/up-sampling with pixel-centre alignment and 11-bit weights, all
+ * integer:  for destination column dx:  num = (2 dx + 1) Ws - Wd, den = 2 Wd, ix = floor(num / den),
+ * wx = round-half-up(2048 (num - ix den) / den); source columns clamp(ix), clamp(ix + 1) (rows alike);
+ * out = (sum of the four products w * p + 2^21) >> 22.  dst: uint8 [n_img, Hd, pitch_d]. */
+int vus_resize_bilinear(const uint8_t* src, int n_img, int Hs, int Ws, int pitch_s, uint8_t* dst,
+                        int Hd, int Wd, int pitch_d, void* stream);
+
+/* Append level `level`'s keypoints (first min(lvl_count, lvl_max_kp) entries of every image, in
+ * order) to the merged per-image lists at slot kp_count[img], up to max_kp; kp_count is advanced.
+ * Before the first level the caller zeroes kp_count and fills kp_keys with VUS_KEY_INVALID.
+ * Positions are mapped to level 0 with pixel-centre alignment, in 1/16 pixel:
+ *   xq = floor(((2 x + 1) * 8 * W0 + Wl / 2) / Wl) - 8   (yq alike; level 0: 16 x),
+ * merged key = score byte of the level key | (y0 * W0 + x0) with x0 = clamp((xq + 8) >> 4, 0, W0-1),
+ * so matchers, vus_track_ids and vus_triangulate see level-0 pixel positions.
+ *   kp_level uint8 [n_img, max_kp] (KeyPoint.octave), kp_xy_q4 int32 [n_img, max_kp, 2] = (xq, yq);
+ *   either may be NULL. */
+int vus_pyramid_append(const uint32_t* lvl_keys, const int* lvl_count, const uint64_t* lvl_desc,
+                       const uint8_t* lvl_angle, int n_img, int lvl_max_kp, int Hl, int Wl, int level,
+                       int H0, int W0, int max_kp, uint32_t* kp_keys, int* kp_count, uint64_t* desc,
+                       uint8_t* angle, uint8_t* kp_level, int32_t* kp_xy_q4, void* stream);
+
 /* Brute-force Hamming matcher over n_pairs (query set, train set) pairs; the query set of pair p
  * is image q_index[p], the train set is image t_index[p] (indices into the [n_img, max_kp] arrays).  For every query keypoint: the train keypoint of smallest Hamming distance
  * among those passing the gates  |yq - yt| <= max_dy  (max_dy < 0: no gate)  and

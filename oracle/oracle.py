@@ -93,6 +93,34 @@ def orient_rbrief(img, blur, kp_keys, kp_count):
     return desc, ang
 
 
+def resize_bilinear(img, Hd, Wd):
+    img, n, H, W = _img_args(img)
+    out = np.empty((n, Hd, Wd), np.uint8)
+    _check(lib().vus_resize_bilinear_cpu(_p(img), n, H, W, W, _p(out), int(Hd), int(Wd), int(Wd)), "resize_bilinear")
+    return out
+
+
+def pyramid_append(lvl_keys, lvl_count, lvl_desc, lvl_angle, Hl, Wl, level, H0, W0, merged):
+    """merged = dict(kp_keys, kp_count, desc, angle, kp_level, kp_xy_q4) of numpy arrays, updated in place."""
+    lvl_keys = np.ascontiguousarray(lvl_keys, np.uint32)
+    lvl_count = np.ascontiguousarray(lvl_count, np.int32)
+    lvl_desc = np.ascontiguousarray(lvl_desc, np.uint64)
+    lvl_angle = np.ascontiguousarray(lvl_angle, np.uint8)
+    n, lk = lvl_keys.shape
+    m = merged
+    _check(lib().vus_pyramid_append_cpu(_p(lvl_keys), _p(lvl_count), _p(lvl_desc), _p(lvl_angle), n, lk, int(Hl), int(Wl),
+                                        int(level), int(H0), int(W0), m["kp_keys"].shape[1], _p(m["kp_keys"]),
+                                        _p(m["kp_count"]), _p(m["desc"]), _p(m["angle"]), _p(m["kp_level"]),
+                                        _p(m["kp_xy_q4"])), "pyramid_append")
+    return m
+
+
+def new_merged(n_img, max_kp):
+    return dict(kp_keys=np.full((n_img, max_kp), 0xFFFFFFFF, np.uint32), kp_count=np.zeros(n_img, np.int32),
+                desc=np.zeros((n_img, max_kp, 4), np.uint64), angle=np.zeros((n_img, max_kp), np.uint8),
+                kp_level=np.zeros((n_img, max_kp), np.uint8), kp_xy_q4=np.zeros((n_img, max_kp, 2), np.int32))
+
+
 def hamming_match(desc, kp_keys, kp_count, W, q_index, t_index, max_dy=-1, min_disp=0, max_disp=0,
                   max_dist=256, H=None):
     desc = np.ascontiguousarray(desc, np.uint64)

@@ -204,6 +204,68 @@ int vus_orient_rbrief_cpu(const uint8_t* img, const uint8_t* blur, int n_img, in
   return VUS_OK;
 }
 
+/* Bilinear resize, integer (include/vus.h: vus_resize_bilinear). */
+static void resize_coeff(int d, int Ns, int Nd, int* i0, int* i1, int* w) {
+  const long long num = (long long)(2 * d + 1) * Ns - Nd, den = 2LL * Nd;
+  long long ix = num >= 0 ? num / den : -((-num + den - 1) / den);   /* floor */
+  const long long rem = num - ix * den;
+  *w = (int)((rem * 2048 + den / 2) / den);
+  *i0 = clampi((int)ix, 0, Ns - 1);
+  *i1 = clampi((int)ix + 1, 0, Ns - 1);
+}
+
+int vus_resize_bilinear_cpu(const uint8_t* src, int n_img, int Hs, int Ws, int pitch_s, uint8_t* dst, int Hd,
+                            int Wd, int pitch_d) {
+  if (!src || !dst || n_img < 0 || Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1 || pitch_s < Ws || pitch_d < Wd)
+    return VUS_E_INVALID;
+  for (int n = 0; n < n_img; ++n) {
+    const uint8_t* s = src + (size_t)n * Hs * pitch_s;
+    uint8_t* d = dst + (size_t)n * Hd * pitch_d;
+    for (int y = 0; y < Hd; ++y) {
+      int y0, y1, wy;
+      resize_coeff(y, Hs, Hd, &y0, &y1, &wy);
+      for (int x = 0; x < Wd; ++x) {
+        int x0, x1, wx;
+        resize_coeff(x, Ws, Wd, &x0, &x1, &wx);
+        const int top = (2048 - wx) * s[(size_t)y0 * pitch_s + x0] + wx * s[(size_t)y0 * pitch_s + x1];
+        const int bot = (2048 - wx) * s[(size_t)y1 * pitch_s + x0] + wx * s[(size_t)y1 * pitch_s + x1];
+        d[(size_t)y * pitch_d + x] = (uint8_t)(((2048 - wy) * top + wy * bot + (1 << 21)) >> 22);
+      }
+    }
+  }
+  return VUS_OK;
+}
+
+/* Level-major merge of the per-level keypoint lists (include/vus.h: vus_pyramid_append). */
+int vus_pyramid_append_cpu(const uint32_t* lvl_keys, const int* lvl_count, const uint64_t* lvl_desc,
+                           const uint8_t* lvl_angle, int n_img, int lvl_max_kp, int Hl, int Wl, int level, int H0,
+                           int W0, int max_kp, uint32_t* kp_keys, int* kp_count, uint64_t* desc, uint8_t* angle,
+                           uint8_t* kp_level, int32_t* kp_xy_q4) {
+  if (!lvl_keys || !lvl_count || !lvl_desc || !lvl_angle || !kp_keys || !kp_count || !desc || !angle ||
+      Hl < 1 || Wl < 1 || H0 < 1 || W0 < 1 || max_kp < 1 || lvl_max_kp < 1 || level < 0 || level > 255)
+    return VUS_E_INVALID;
+  for (int n = 0; n < n_img; ++n) {
+    const int base = kp_count[n];
+    int cnt = lvl_count[n] < lvl_max_kp ? lvl_count[n] : lvl_max_kp;
+    if (cnt > max_kp - base) cnt = max_kp - base;
+    for (int t = 0; t < cnt; ++t) {
+      const uint32_t key = lvl_keys[(size_t)n * lvl_max_kp + t];
+      const int pos = (int)(key & VUS_KEY_POS_MASK), y = pos / Wl, x = pos - y * Wl;
+      const int xq = (int)((((long long)(2 * x + 1) * 8 * W0 + Wl / 2) / Wl) - 8);
+      const int yq = (int)((((long long)(2 * y + 1) * 8 * H0 + Hl / 2) / Hl) - 8);
+      const int x0 = clampi((xq + 8) >> 4, 0, W0 - 1), y0 = clampi((yq + 8) >> 4, 0, H0 - 1);
+      const size_t o = (size_t)n * max_kp + base + t;
+      kp_keys[o] = (key & ~VUS_KEY_POS_MASK) | (uint32_t)(y0 * W0 + x0);
+      for (int w = 0; w < 4; ++w) desc[4 * o + w] = lvl_desc[4 * ((size_t)n * lvl_max_kp + t) + w];
+      angle[o] = lvl_angle[(size_t)n * lvl_max_kp + t];
+      if (kp_level) kp_level[o] = (uint8_t)level;
+      if (kp_xy_q4) { kp_xy_q4[2 * o] = xq; kp_xy_q4[2 * o + 1] = yq; }
+    }
+    kp_count[n] = base + cnt;
+  }
+  return VUS_OK;
+}
+
 int vus_hamming_match_cpu(const uint64_t* desc, const uint32_t* kp_keys, const int* kp_count,
                           int max_kp, int H, int W, const int* q_index, const int* t_index, int n_pairs,
                           int max_dy, int min_disp, int max_disp, int max_dist,

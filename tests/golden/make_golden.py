@@ -30,6 +30,27 @@ def frontend():
                         kp_keys=kp, kp_count=kc, desc=desc, angle=ang, match_idx=idx, match_dist=dist)
 
 
+def pyramid():
+    from visual_underwater_slam_amd.frontend import pyramid_layout
+    img = synth.stereo_frames(42, 1, H=96, W=128)[0]
+    sizes, quotas = pyramid_layout(96, 128, 64, 3, 1.2)
+    m = O.new_merged(2, 64)
+    lvl, lv_imgs = img, []
+    for l, ((h, w), q) in enumerate(zip(sizes, quotas)):
+        if l > 0:
+            lvl = O.resize_bilinear(lvl, h, w)
+            lv_imgs.append(lvl)
+        ck, cc, blur = O.fast_detect(lvl, thr=10, border=20, cand_cap=2048)
+        kp, kc = O.select_topk(ck, cc, q)
+        desc, ang = O.orient_rbrief(lvl, blur, kp, kc)
+        O.pyramid_append(kp, kc, desc, ang, h, w, l, 96, 128, m)
+    c = m["kp_count"]
+    for n in range(2):           # slots past the count are unspecified: zero them in the fixture
+        m["desc"][n, c[n]:] = 0; m["angle"][n, c[n]:] = 0; m["kp_level"][n, c[n]:] = 0; m["kp_xy_q4"][n, c[n]:] = 0
+    np.savez_compressed(os.path.join(HERE, "pyramid_96x128.npz"), img=img, level1=lv_imgs[0], level2=lv_imgs[1],
+                        sizes=np.array(sizes), quotas=np.array(quotas), **m)
+
+
 def ba():
     rng = np.random.default_rng(20261004)
     K = np.array([1827.0, 1827.5999755859375, 0.0, 968.9000244140625, 561.4000244140625, 0.063])
@@ -62,6 +83,7 @@ def ba():
 
 if __name__ == "__main__":
     frontend()
+    pyramid()
     ba()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

@@ -317,3 +317,79 @@ def test_pipeline_edge_cases_single_frame_and_featureless_images(gpu, oracle):
     assert (res.stereo_idx.cpu().numpy() == -1).all() and (res.stereo_dist.cpu().numpy() == 512).all()
     assert res.track_idx.shape[0] == 0 and n_ids == 0 and (ids.cpu().numpy() == -1).all()
     assert fe.camera_measurements(res)[0].features == []
+
+
+# ---------------------------------------------------------------------------------------------
+# optional ORB scale pyramid
+@pytest.mark.parametrize("src,dst", [((40, 56), (40, 56)), ((40, 56), (20, 28)), ((720, 1280), (600, 1067)),
+                                      ((201, 357), (168, 298)), ((37, 53), (61, 90))])
+def test_resize_bilinear_bit_exact(gpu, oracle, src, dst):
+    import visual_underwater_slam_amd._lib as L
+    rng = np.random.default_rng(src[0] + dst[1])
+    img = rng.integers(0, 256, size=(3,) + src, dtype=np.uint8)
+    d = _dev(img)
+    pitch_d = dst[1] + 5                                     # destination rows are padded
+    out = torch.zeros((3, dst[0], pitch_d), dtype=torch.uint8, device="cuda")
+    L.call("vus_resize_bilinear", d.data_ptr(), 3, src[0], src[1], src[1], out.data_ptr(), dst[0], dst[1], pitch_d,
+           L.current_stream_ptr())
+    torch.cuda.synchronize()
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :, :dst[1]], oracle.resize_bilinear(img, *dst))
+    assert not got[:, :, dst[1]:].any()                      # the padding is not written
+
+
+def _pyramid_oracle(oracle, flat, p, H, W):
+    """The oracle's stages chained level by level (host logic restated independently of frontend.py)."""
+    from visual_underwater_slam_amd.frontend import pyramid_layout
+    sizes, quotas = pyramid_layout(H, W, p.max_features, p.n_levels, p.scale_factor)
+    m = oracle.new_merged(flat.shape[0], p.max_features)
+    lvl = flat
+    for l, ((h, w), q) in enumerate(zip(sizes, quotas)):
+        if l > 0:
+            lvl = oracle.resize_bilinear(lvl, h, w)
+        ck, cc, blur = oracle.fast_detect(lvl, p.fast_threshold, p.border, p.cand_cap)
+        kp, kc = oracle.select_topk(ck, cc, max(q, 1))
+        desc, ang = oracle.orient_rbrief(lvl, blur, kp, kc)
+        oracle.pyramid_append(kp, kc, desc, ang, h, w, l, H, W, m)
+    return m
+
+
+@pytest.mark.parametrize("shape,levels,kmax", [((240, 320), 4, 600), ((720, 1280), 8, 2000)])
+def test_pyramid_pipeline_matches_oracle_chain(gpu, oracle, shape, levels, kmax):
+    """n_levels > 1: merged keypoints, levels, sub-pixel positions, descriptors and both match sets are bit-exact."""
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    H, W = shape
+    F = 2
+    img = synth.stereo_frames(7, F)[:, :, :H, :W].copy()
+    p = ImageProcessorParams(n_levels=levels, max_features=kmax)
+    fe = StereoOrbFrontend(H, W, max_frames=F, params=p)
+    res = fe.process(torch.from_numpy(img).cuda())
+    torch.cuda.synchronize()
+    m = _pyramid_oracle(oracle, img.reshape(2 * F, H, W), p, H, W)
+    kc = m["kp_count"]
+    assert np.array_equal(res.kp_count.cpu().numpy(), kc) and kc.min() > 100
+    assert np.array_equal(_u32(res.kp_keys), m["kp_keys"])
+    gd, ga = res.desc.cpu().numpy().view(np.uint64), res.angle.cpu().numpy()
+    gl, gq = res.kp_level.cpu().numpy(), res.kp_xy_q4.cpu().numpy()
+    for n in range(2 * F):
+        c = kc[n]
+        assert np.array_equal(gd[n, :c], m["desc"][n, :c]) and np.array_equal(ga[n, :c], m["angle"][n, :c])
+        assert np.array_equal(gl[n, :c], m["kp_level"][n, :c]) and np.array_equal(gq[n, :c], m["kp_xy_q4"][n, :c])
+    assert len(np.unique(m["kp_level"][0, :kc[0]])) == levels         # every level contributes
+    f = np.arange(F, dtype=np.int32)
+    desc = m["desc"].copy()
+    sidx, sdist = oracle.hamming_match(desc, m["kp_keys"], kc, W, 2 * f, 2 * f + 1, p.stereo_threshold,
+                                       p.min_disparity, p.max_disparity, p.stereo_max_distance, H=H)
+    tidx, tdist = oracle.hamming_match(desc, m["kp_keys"], kc, W, 2 * f[:-1], 2 * f[:-1] + 2, -1, 0, 0,
+                                       p.track_max_distance, H=H)
+
+    def same_matches(gi, gdist, oi, od, q_imgs):
+        for r, qi in enumerate(q_imgs):
+            c = kc[qi]
+            assert np.array_equal(gi[r, :c], oi[r, :c]) and np.array_equal(gdist[r, :c], od[r, :c])
+
+    same_matches(res.stereo_idx.cpu().numpy(), res.stereo_dist.cpu().numpy(), sidx, sdist, 2 * f)
+    same_matches(res.track_idx.cpu().numpy(), res.track_dist.cpu().numpy(), tidx, tdist, 2 * f[:-1])
+    assert (sidx[0, :kc[0]] >= 0).sum() > 50
+    msgs = fe.camera_measurements(res)
+    assert len(msgs) == F and len(msgs[0].features) > 50

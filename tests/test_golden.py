@@ -26,6 +26,39 @@ def test_oracle_reproduces_frontend_golden(oracle):
     assert (idx[1, :kc[0]] == np.arange(kc[0])).all()        # self-match row
 
 
+def _pyramid_chain(oracle, g):
+    from visual_underwater_slam_amd.frontend import pyramid_layout
+    sizes, quotas = pyramid_layout(96, 128, 64, 3, 1.2)
+    assert np.array_equal(np.array(sizes), g["sizes"]) and np.array_equal(np.array(quotas), g["quotas"])
+    m = oracle.new_merged(2, 64)
+    lvl, imgs = g["img"], []
+    for l, ((h, w), q) in enumerate(zip(sizes, quotas)):
+        if l > 0:
+            lvl = oracle.resize_bilinear(lvl, h, w)
+            imgs.append(lvl)
+        ck, cc, blur = oracle.fast_detect(lvl, thr=10, border=20, cand_cap=2048)
+        kp, kc = oracle.select_topk(ck, cc, q)
+        desc, ang = oracle.orient_rbrief(lvl, blur, kp, kc)
+        oracle.pyramid_append(kp, kc, desc, ang, h, w, l, 96, 128, m)
+    return m, imgs
+
+
+def _same_merged(got, g):
+    c = g["kp_count"]
+    assert np.array_equal(got["kp_count"], c) and np.array_equal(got["kp_keys"], g["kp_keys"]) and c.min() > 20
+    for n in range(2):
+        for k in ("desc", "angle", "kp_level", "kp_xy_q4"):
+            assert np.array_equal(got[k][n, :c[n]], g[k][n, :c[n]]), k
+
+
+def test_oracle_reproduces_pyramid_golden(oracle):
+    g = np.load(os.path.join(G, "pyramid_96x128.npz"))
+    m, imgs = _pyramid_chain(oracle, g)
+    assert np.array_equal(imgs[0], g["level1"]) and np.array_equal(imgs[1], g["level2"])
+    _same_merged(m, g)
+    assert set(np.unique(g["kp_level"][0, :g["kp_count"][0]])) == {0, 1, 2}
+
+
 def test_oracle_reproduces_ba_golden(oracle):
     g = np.load(os.path.join(G, "ba_c1.npz"))
     for i in range(8):
@@ -57,6 +90,22 @@ def test_hip_frontend_hits_golden(gpu):
     assert np.array_equal(fe.blur.cpu().numpy(), g["blur"])
     assert np.array_equal(res.stereo_idx.cpu().numpy()[0], g["match_idx"][0])
     assert np.array_equal(res.stereo_dist.cpu().numpy()[0], g["match_dist"][0])
+
+
+@pytest.mark.gpu
+def test_hip_pyramid_hits_golden(gpu):
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    g = np.load(os.path.join(G, "pyramid_96x128.npz"))
+    prm = ImageProcessorParams(max_features=64, border=20, cand_cap=2048, n_levels=3)
+    fe = StereoOrbFrontend(96, 128, max_frames=1, params=prm)
+    res = fe.process(torch.from_numpy(g["img"][None]).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(fe.levels[1]["img"].cpu().numpy(), g["level1"])
+    assert np.array_equal(fe.levels[2]["img"].cpu().numpy(), g["level2"])
+    got = dict(kp_keys=res.kp_keys.cpu().numpy().view(np.uint32), kp_count=res.kp_count.cpu().numpy(),
+               desc=res.desc.cpu().numpy().view(np.uint64), angle=res.angle.cpu().numpy(),
+               kp_level=res.kp_level.cpu().numpy(), kp_xy_q4=res.kp_xy_q4.cpu().numpy())
+    _same_merged(got, g)
 
 
 @pytest.mark.gpu

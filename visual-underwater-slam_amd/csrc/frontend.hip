@@ -888,6 +888,130 @@ TileGrid tile_grid(int n_img, int H, int W) {
   return TileGrid{(unsigned)(((n_img + 7) / 8) * 8 * tx * ty), tx, tx * ty};
 }
 
+// ---------------------------------------------------------------------------------------------
+// optional scale pyramid: bilinear resize (11-bit weights, pixel-centre alignment) and the
+// level-major merge of per-level keypoints (include/vus.h)
+// all quantities fit 32 bits for images up to 2^24 pixels: num < 2 Ns Nd, rem * 2048 < 2^12 Nd
+__device__ __forceinline__ void resize_coeff(int d, int Ns, int Nd, int& i0, int& i1, int& w) {
+  const int num = (2 * d + 1) * Ns - Nd, den = 2 * Nd;
+  const int ix = num >= 0 ? (int)((unsigned)num / (unsigned)den) : -(int)((unsigned)(-num + den - 1) / (unsigned)den);
+  const unsigned rem = (unsigned)(num - ix * den);
+  w = (int)((rem * 2048u + (unsigned)Nd) / (unsigned)den);
+  i0 = min(max(ix, 0), Ns - 1);
+  i1 = min(max(ix + 1, 0), Ns - 1);
+}
+
+// One thread per 4 destination columns of an RS_ROWS-row strip.  The kernel is bound by the number of
+// vector-memory instructions (a wave-wide byte load costs the texture path as much as a dword load), so
+// a thread fetches the 12 source bytes that cover its 4 columns as three (unaligned) dwords per source
+// row and stores one dword; the byte selectors are row-independent.  Column coefficients are computed
+// once per thread, row coefficients once per workgroup (LDS).  Threads whose columns span more than 12
+// source bytes (scale > 2) fall back to byte loads.
+constexpr int RS_ROWS = 8;
+__device__ __forceinline__ uint32_t window_byte(uint32_t w0, uint32_t w1, uint32_t w2, int o) {
+  const uint32_t sel = o < 4 ? w0 : (o < 8 ? w1 : w2);
+  return (sel >> (8 * (o & 3))) & 0xFFu;
+}
+
+constexpr int RS_THREADS = 64;   // 256 columns per workgroup: little waste on rows that are not a multiple of 1024
+__global__ __launch_bounds__(RS_THREADS) void resize_bilinear_kernel(const uint8_t* __restrict__ src, int Hs, int Ws,
+                                                              int pitch_s, uint8_t* __restrict__ dst, int Hd, int Wd,
+                                                              int pitch_d) {
+  __shared__ int s_y[RS_ROWS][3];
+  const int xb = 4 * (blockIdx.x * RS_THREADS + threadIdx.x);
+  const int ys = blockIdx.y * RS_ROWS;
+  if (threadIdx.x < RS_ROWS) {
+    int y0, y1, wy;
+    resize_coeff(min(ys + (int)threadIdx.x, Hd - 1), Hs, Hd, y0, y1, wy);
+    s_y[threadIdx.x][0] = y0 * pitch_s;
+    s_y[threadIdx.x][1] = y1 * pitch_s;
+    s_y[threadIdx.x][2] = wy;
+  }
+  __syncthreads();
+  if (xb >= Wd) return;
+  const uint8_t* s = src + (size_t)blockIdx.z * Hs * pitch_s;
+  uint8_t* d = dst + (size_t)blockIdx.z * Hd * pitch_d;
+  int x0[4], x1[4], wx[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) resize_coeff(min(xb + j, Wd - 1), Ws, Wd, x0[j], x1[j], wx[j]);
+  const int start = max(min(x0[0], Ws - 12), 0);
+  const bool windowed = Ws >= 12 && x1[3] - start < 12;
+  int o0[4], o1[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    o0[j] = x0[j] - start;
+    o1[j] = x1[j] - start;
+  }
+  const int nx = min(4, Wd - xb);
+#pragma unroll 2
+  for (int r = 0; r < RS_ROWS; ++r) {
+    const int y = ys + r;
+    if (y >= Hd) break;
+    const int r0 = s_y[r][0], r1 = s_y[r][1], wy = s_y[r][2];
+    uint32_t out[4];
+    if (windowed) {
+      uint32_t t[3], b[3];
+      __builtin_memcpy(t, s + r0 + start, 12);
+      __builtin_memcpy(b, s + r1 + start, 12);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int top = (2048 - wx[j]) * (int)window_byte(t[0], t[1], t[2], o0[j]) + wx[j] * (int)window_byte(t[0], t[1], t[2], o1[j]);
+        const int bot = (2048 - wx[j]) * (int)window_byte(b[0], b[1], b[2], o0[j]) + wx[j] * (int)window_byte(b[0], b[1], b[2], o1[j]);
+        out[j] = (uint32_t)(((2048 - wy) * top + wy * bot + (1 << 21)) >> 22);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int top = (2048 - wx[j]) * s[r0 + x0[j]] + wx[j] * s[r0 + x1[j]];
+        const int bot = (2048 - wx[j]) * s[r1 + x0[j]] + wx[j] * s[r1 + x1[j]];
+        out[j] = (uint32_t)(((2048 - wy) * top + wy * bot + (1 << 21)) >> 22);
+      }
+    }
+    uint8_t* o = d + (size_t)y * pitch_d + xb;
+    if (nx == 4) {   // one (possibly unaligned) dword store
+      const uint32_t packed = out[0] | (out[1] << 8) | (out[2] << 16) | (out[3] << 24);
+      __builtin_memcpy(o, &packed, 4);
+    } else {
+      for (int j = 0; j < nx; ++j) o[j] = (uint8_t)out[j];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void pyramid_append_kernel(const uint32_t* __restrict__ lvl_keys,
+                                                             const int* __restrict__ lvl_count,
+                                                             const uint64_t* __restrict__ lvl_desc,
+                                                             const uint8_t* __restrict__ lvl_angle, int lvl_max_kp,
+                                                             int Hl, int Wl, int level, int H0, int W0, int max_kp,
+                                                             uint32_t* __restrict__ kp_keys, int* __restrict__ kp_count,
+                                                             uint64_t* __restrict__ desc, uint8_t* __restrict__ angle,
+                                                             uint8_t* __restrict__ kp_level,
+                                                             int32_t* __restrict__ kp_xy_q4) {
+  const int n = blockIdx.x;
+  const int base = kp_count[n];
+  int cnt = min(lvl_count[n], lvl_max_kp);
+  cnt = min(cnt, max_kp - base);
+  __syncthreads();   // every thread has read the old count
+  for (int t = threadIdx.x; t < cnt; t += 256) {
+    const size_t li = (size_t)n * lvl_max_kp + t;
+    const uint32_t key = lvl_keys[li];
+    const int pos = (int)(key & VUS_KEY_POS_MASK), y = pos / Wl, x = pos - y * Wl;
+    const int xq = (int)((((long long)(2 * x + 1) * 8 * W0 + Wl / 2) / Wl) - 8);
+    const int yq = (int)((((long long)(2 * y + 1) * 8 * H0 + Hl / 2) / Hl) - 8);
+    const int x0 = min(max((xq + 8) >> 4, 0), W0 - 1), y0 = min(max((yq + 8) >> 4, 0), H0 - 1);
+    const size_t o = (size_t)n * max_kp + base + t;
+    kp_keys[o] = (key & ~VUS_KEY_POS_MASK) | (uint32_t)(y0 * W0 + x0);
+#pragma unroll
+    for (int w = 0; w < 4; ++w) desc[4 * o + w] = lvl_desc[4 * li + w];
+    angle[o] = lvl_angle[li];
+    if (kp_level) kp_level[o] = (uint8_t)level;
+    if (kp_xy_q4) {
+      kp_xy_q4[2 * o] = xq;
+      kp_xy_q4[2 * o + 1] = yq;
+    }
+  }
+  if (threadIdx.x == 0) kp_count[n] = base + cnt;
+}
+
 }  // namespace
 
 extern "C" int vus_fast_score(const uint8_t* img, int n_img, int H, int W, int pitch, int thr,
@@ -1023,5 +1147,36 @@ extern "C" int vus_triangulate(const double* feat, int n, const double* cam, con
   if (n == 0) return VUS_OK;
   triangulate_kernel<<<(n + 255) / 256, 256, 0, vus::as_stream(stream)>>>(feat, n, cam, Rt, out);
   VUS_CHECK_LAUNCH("triangulate");
+  return VUS_OK;
+}
+
+extern "C" int vus_resize_bilinear(const uint8_t* src, int n_img, int Hs, int Ws, int pitch_s, uint8_t* dst, int Hd,
+                                   int Wd, int pitch_d, void* stream) {
+  if (int rc = check_image_args(src, n_img, Hs, Ws, pitch_s)) return rc;
+  VUS_REQUIRE(dst != nullptr, "dst is null");
+  VUS_REQUIRE(Hd >= 1 && Wd >= 1 && pitch_d >= Wd, "bad destination size %dx%d pitch %d", Hd, Wd, pitch_d);
+  if (n_img == 0) return VUS_OK;
+  VUS_REQUIRE(n_img <= 65535, "n_img=%d exceeds the grid's z extent", n_img);
+  const dim3 grid((Wd + 4 * RS_THREADS - 1) / (4 * RS_THREADS), (Hd + RS_ROWS - 1) / RS_ROWS, n_img);
+  resize_bilinear_kernel<<<grid, RS_THREADS, 0, vus::as_stream(stream)>>>(src, Hs, Ws, pitch_s, dst, Hd, Wd, pitch_d);
+  VUS_CHECK_LAUNCH("resize_bilinear");
+  return VUS_OK;
+}
+
+extern "C" int vus_pyramid_append(const uint32_t* lvl_keys, const int* lvl_count, const uint64_t* lvl_desc,
+                                  const uint8_t* lvl_angle, int n_img, int lvl_max_kp, int Hl, int Wl, int level,
+                                  int H0, int W0, int max_kp, uint32_t* kp_keys, int* kp_count, uint64_t* desc,
+                                  uint8_t* angle, uint8_t* kp_level, int32_t* kp_xy_q4, void* stream) {
+  VUS_REQUIRE(lvl_keys && lvl_count && lvl_desc && lvl_angle && kp_keys && kp_count && desc && angle, "null buffer");
+  VUS_REQUIRE(n_img >= 0 && lvl_max_kp >= 1 && max_kp >= 1, "bad sizes: n_img=%d lvl_max_kp=%d max_kp=%d", n_img,
+              lvl_max_kp, max_kp);
+  VUS_REQUIRE(Hl >= 1 && Wl >= 1 && H0 >= 1 && W0 >= 1 && (long long)H0 * W0 <= (1ll << VUS_KEY_POS_BITS),
+              "bad image sizes: level %dx%d, base %dx%d", Hl, Wl, H0, W0);
+  VUS_REQUIRE(level >= 0 && level <= 255, "level=%d", level);
+  if (n_img == 0) return VUS_OK;
+  pyramid_append_kernel<<<n_img, 256, 0, vus::as_stream(stream)>>>(lvl_keys, lvl_count, lvl_desc, lvl_angle, lvl_max_kp,
+                                                                   Hl, Wl, level, H0, W0, max_kp, kp_keys, kp_count,
+                                                                   desc, angle, kp_level, kp_xy_q4);
+  VUS_CHECK_LAUNCH("pyramid_append");
   return VUS_OK;
 }

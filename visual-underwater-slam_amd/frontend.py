@@ -30,6 +30,26 @@ class ImageProcessorParams:
     stereo_max_distance: int = 64  # Hamming acceptance thresholds
     track_max_distance: int = 64
     cand_cap: int = 32768          # candidate slots per image before top-K selection
+    n_levels: int = 1              # ORB scale pyramid: 1 = single level; 8 with scale_factor 1.2 = Rublee et al.
+    scale_factor: float = 1.2
+
+
+def pyramid_layout(H: int, W: int, max_features: int, n_levels: int, scale_factor: float):
+    """Level sizes and per-level keypoint quotas of the ORB pyramid (ORB paper sec. 6.1; the quota rule is the
+    usual geometric split: level l gets a share proportional to scale_factor**-l, the last level the remainder)."""
+    sizes = [(int(round(H / scale_factor ** l)), int(round(W / scale_factor ** l))) for l in range(n_levels)]
+    if n_levels == 1:
+        return sizes, [max_features]
+    f = 1.0 / scale_factor
+    nd = max_features * (1.0 - f) / (1.0 - f ** n_levels)
+    quotas, total = [], 0
+    for _ in range(n_levels - 1):
+        q = int(round(nd))
+        quotas.append(q)
+        total += q
+        nd *= f
+    quotas.append(max(max_features - total, 0))
+    return sizes, quotas
 
 
 @dataclass
@@ -62,6 +82,8 @@ class FrontendResult:
         self.cand_count = fe.cand_count[:2 * F]
         self.stereo_idx = fe.match_idx[:F]
         self.stereo_dist = fe.match_dist[:F]
+        self.kp_level = fe.kp_level[:2 * F] if fe.kp_level is not None else None       # pyramid mode only
+        self.kp_xy_q4 = fe.kp_xy_q4[:2 * F] if fe.kp_xy_q4 is not None else None       # level-0 position, 1/16 px
         self.track_idx = fe.match_idx[fe.max_frames:fe.max_frames + max(F - 1, 0)]
         self.track_dist = fe.match_dist[fe.max_frames:fe.max_frames + max(F - 1, 0)]
 
@@ -103,6 +125,26 @@ class StereoOrbFrontend:
         f = torch.arange(self.max_frames, dtype=torch.int32, device=dev)
         self.stereo_q, self.stereo_t = (2 * f).contiguous(), (2 * f + 1).contiguous()
         self.track_q, self.track_t = (2 * f).contiguous(), (2 * f + 2).contiguous()
+        self.kp_level = self.kp_xy_q4 = None
+        self.levels = None
+        if self.p.n_levels > 1:
+            # per-level workspaces: image (levels >= 1), smoothed image, keys, descriptors
+            sizes, quotas = pyramid_layout(H, W, K, self.p.n_levels, self.p.scale_factor)
+            assert all(h >= 2 * self.p.border + 8 and w >= 2 * self.p.border + 8 for h, w in sizes), \
+                "pyramid level smaller than the detector border"
+            self.kp_level = torch.zeros((n_img, K), dtype=torch.uint8, device=dev)
+            self.kp_xy_q4 = torch.zeros((n_img, K, 2), dtype=torch.int32, device=dev)
+            self.levels = []
+            for l, ((h, w), q) in enumerate(zip(sizes, quotas)):
+                q = max(q, 1)
+                self.levels.append(dict(
+                    H=h, W=w, quota=q,
+                    img=None if l == 0 else torch.empty((n_img, h, w), dtype=torch.uint8, device=dev),
+                    blur=self.blur if l == 0 else torch.empty((n_img, h, w), dtype=torch.uint8, device=dev),
+                    keys=torch.empty((n_img, q), dtype=torch.int32, device=dev),
+                    count=torch.zeros((n_img,), dtype=torch.int32, device=dev),
+                    desc=torch.empty((n_img, q, 4), dtype=torch.int64, device=dev),
+                    angle=torch.empty((n_img, q), dtype=torch.uint8, device=dev)))
 
     def process(self, images: torch.Tensor, check: bool = True) -> FrontendResult:
         """images: uint8 [F, 2, H, W] on the GPU (index 1: 0 = left / cam0, 1 = right / cam1).
@@ -114,13 +156,16 @@ class StereoOrbFrontend:
         n_img = 2 * F
         st = _lib.current_stream_ptr()
         ptr = _lib.ptr
-        self.cand_count[:n_img].zero_()
-        _lib.call("vus_fast_detect", ptr(images), n_img, H, W, W, p.fast_threshold, p.border,
-                  ptr(self.blur), ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
-        _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, K,
-                  ptr(self.kp_keys), ptr(self.kp_count), st)
-        _lib.call("vus_orient_rbrief", ptr(images), ptr(self.blur), n_img, H, W, W, ptr(self.kp_keys),
-                  ptr(self.kp_count), K, ptr(self.desc), ptr(self.angle), st)
+        if self.levels is None:
+            self.cand_count[:n_img].zero_()
+            _lib.call("vus_fast_detect", ptr(images), n_img, H, W, W, p.fast_threshold, p.border,
+                      ptr(self.blur), ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
+            _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, K,
+                      ptr(self.kp_keys), ptr(self.kp_count), st)
+            _lib.call("vus_orient_rbrief", ptr(images), ptr(self.blur), n_img, H, W, W, ptr(self.kp_keys),
+                      ptr(self.kp_count), K, ptr(self.desc), ptr(self.angle), st)
+        else:
+            self._process_pyramid(images, n_img, st)
         _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, H, W,
                   ptr(self.stereo_q), ptr(self.stereo_t), F, p.stereo_threshold, p.min_disparity,
                   p.max_disparity, p.stereo_max_distance, ptr(self.match_idx), ptr(self.match_dist), st)
@@ -132,7 +177,38 @@ class StereoOrbFrontend:
             self.check_overflow(n_img)
         return FrontendResult(self, F)
 
+    def _process_pyramid(self, images, n_img, st):
+        """Detect / select / describe on every level, then merge level-major into the per-image lists."""
+        p, K, ptr = self.p, self.p.max_features, _lib.ptr
+        self.kp_count[:n_img].zero_()
+        self.kp_keys[:n_img].fill_(-1)          # VUS_KEY_INVALID
+        self.pyr_cand_max = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        prev = images
+        for l, L in enumerate(self.levels):
+            h, w = L["H"], L["W"]
+            if l > 0:
+                P = self.levels[l - 1]
+                _lib.call("vus_resize_bilinear", ptr(prev), n_img, P["H"], P["W"], P["W"], ptr(L["img"]), h, w, w, st)
+                prev = L["img"]
+            self.cand_count[:n_img].zero_()
+            _lib.call("vus_fast_detect", ptr(prev), n_img, h, w, w, p.fast_threshold, p.border, ptr(L["blur"]),
+                      ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
+            torch.maximum(self.pyr_cand_max, self.cand_count[:n_img].max().reshape(1), out=self.pyr_cand_max)
+            _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, L["quota"],
+                      ptr(L["keys"]), ptr(L["count"]), st)
+            _lib.call("vus_orient_rbrief", ptr(prev), ptr(L["blur"]), n_img, h, w, w, ptr(L["keys"]), ptr(L["count"]),
+                      L["quota"], ptr(L["desc"]), ptr(L["angle"]), st)
+            _lib.call("vus_pyramid_append", ptr(L["keys"]), ptr(L["count"]), ptr(L["desc"]), ptr(L["angle"]), n_img,
+                      L["quota"], h, w, l, self.H, self.W, K, ptr(self.kp_keys), ptr(self.kp_count), ptr(self.desc),
+                      ptr(self.angle), ptr(self.kp_level), ptr(self.kp_xy_q4), st)
+
     def check_overflow(self, n_img=None):
+        if self.levels is not None:
+            worst = int(self.pyr_cand_max.item())
+            if worst > self.p.cand_cap:
+                raise _lib.VusError(f"FAST produced {worst} candidates in one pyramid level, more than cand_cap="
+                                    f"{self.p.cand_cap}: raise ImageProcessorParams.cand_cap")
+            return
         n_img = self.cand_count.shape[0] if n_img is None else n_img
         worst = int(self.cand_count[:n_img].max().item())
         if worst > self.p.cand_cap:
