@@ -889,6 +889,134 @@ TileGrid tile_grid(int n_img, int H, int W) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// Ungated brute-force matcher on the matrix cores.  With the descriptor bits as +-1 int8 values,
+// dot(q, t) = 256 - 2 * Hamming(q, t) exactly, so argmin Hamming = argmax dot: the 2000 x 2000 x 256-bit
+// all-pairs problem of one image pair is an int8 GEMM (v_mfma_i32_32x32x32_i8; the VALU version is
+// bound by the v_bcnt issue rate).  Rows of a 32x32 tile = train descriptors (A operand, expanded into
+// LDS once per 128-train chunk and shared by the four waves), columns = the wave's 32 queries (B
+// operand, expanded once into registers).  A and B use the same lane -> k map, so only the C layout
+// (col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) matters.  Epilogue: one key per
+// value, (dot << 16) | (0xFFFF - train index), running signed max = smallest distance, ties to the
+// lowest train index -- the brute-force result, bit for bit.
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+typedef int v16i_t __attribute__((ext_vector_type(16)));
+constexpr int HM_CHUNK = 128;        // trains expanded per LDS chunk
+constexpr int HM_ROWB = 272;         // bytes per expanded row: 256 + 16 (bank spread of the b128 reads)
+
+// 4 descriptor bits -> 4 bytes of +1 (bit set) / -1
+__device__ __forceinline__ int spread_pm1(uint32_t nib) {
+  const uint32_t sp = (nib * 0x00204081u) & 0x01010101u;
+  return (int)~(sp * 0xFEu);
+}
+
+constexpr int HM_QT = 2;             // 32-query column tiles per wave (A fragments and the chunk expansion are shared)
+constexpr int HM_QWG = 4 * 32 * HM_QT;   // queries per workgroup
+
+// best key of one 32x32 tile for this lane's query: per value (dot << 5) | (31 - row) with the row as an
+// inline constant, a max3 tree, then one conversion to the global key (dot << 16) | (0xFFFF - train index)
+__device__ __forceinline__ int tile_best(const v16i_t& acc, int tb) {
+  int k[16];
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) k[reg] = acc[reg] * 32 + (31 - ((reg & 3) + 8 * (reg >> 2)));
+  const int m0 = max3i(k[0], k[1], k[2]), m1 = max3i(k[3], k[4], k[5]), m2 = max3i(k[6], k[7], k[8]),
+            m3 = max3i(k[9], k[10], k[11]), m4 = max3i(k[12], k[13], k[14]);
+  const int m = max(max3i(m0, m1, m2), max3i(m3, m4, k[15]));
+  const int row = 31 - (m & 31);
+  return (m >> 5) * 65536 + (0xFFFF - (tb + row));
+}
+
+__global__ __launch_bounds__(256) void hamming_match_mfma_kernel(const uint32_t* __restrict__ desc32,
+                                                                 const int* __restrict__ kp_count, int max_kp,
+                                                                 const int* __restrict__ q_index,
+                                                                 const int* __restrict__ t_index, int max_dist,
+                                                                 int32_t* __restrict__ idx_out,
+                                                                 int32_t* __restrict__ dist_out) {
+  __shared__ __attribute__((aligned(16))) uint8_t s_t[HM_CHUNK * HM_ROWB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int p = blockIdx.y;
+  const int qi = q_index[p], ti = t_index[p];
+  const int nq = kp_count[qi], nt = kp_count[ti];
+  const int q0 = blockIdx.x * HM_QWG + 32 * HM_QT * wave + r;   // column tile c holds query q0 + 32 c
+  // B fragments: k-step ks, lane half h <-> descriptor bits [32 ks + 16 h, +16)
+  v4i_t bq[HM_QT][8];
+#pragma unroll
+  for (int c = 0; c < HM_QT; ++c) {
+    const int q = q0 + 32 * c;
+    const uint32_t* dq = desc32 + ((size_t)qi * max_kp + min(q, max_kp - 1)) * 8;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      const uint32_t bits = (q < nq ? dq[ks] : 0u) >> (16 * h);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bq[c][ks][n] = spread_pm1((bits >> (4 * n)) & 0xFu);
+    }
+  }
+  int best[HM_QT];
+#pragma unroll
+  for (int c = 0; c < HM_QT; ++c) best[c] = INT_MIN;
+  const uint32_t* dt = desc32 + (size_t)ti * max_kp * 8;
+  for (int t0 = 0; t0 < nt; t0 += HM_CHUNK) {
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < HM_CHUNK * 8 / 256; ++u) {   // (train, 32-bit word) items
+      const int item = tid + 256 * u;
+      const int tr = item >> 3, wd = item & 7;
+      const uint32_t x = t0 + tr < nt ? dt[(size_t)(t0 + tr) * 8 + wd] : 0u;
+      v4i_t lo, hi;
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        lo[n] = spread_pm1((x >> (4 * n)) & 0xFu);
+        hi[n] = spread_pm1((x >> (16 + 4 * n)) & 0xFu);
+      }
+      v4i_t* dst = reinterpret_cast<v4i_t*>(s_t + tr * HM_ROWB + 32 * wd);
+      dst[0] = lo;
+      dst[1] = hi;
+    }
+    __syncthreads();
+    const int ntile = min(HM_CHUNK, nt - t0 + 31) >> 5;
+    for (int tile = 0; tile < ntile; ++tile) {
+      const uint8_t* arow = s_t + (32 * tile + r) * HM_ROWB + 16 * h;
+      v16i_t acc[HM_QT];
+#pragma unroll
+      for (int c = 0; c < HM_QT; ++c) acc[c] = v16i_t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int ks = 0; ks < 8; ++ks) {
+        const v4i_t a = *reinterpret_cast<const v4i_t*>(arow + 32 * ks);
+#pragma unroll
+        for (int c = 0; c < HM_QT; ++c) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[c][ks], acc[c], 0, 0, 0);
+      }
+      const int tb = t0 + 32 * tile + 4 * h;            // train index of this lane's row 0
+      if (t0 + 32 * tile + 32 > nt) {                   // wave-uniform: rows past the train count cannot win
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+          if (tb + (reg & 3) + 8 * (reg >> 2) >= nt) {
+#pragma unroll
+            for (int c = 0; c < HM_QT; ++c) acc[c][reg] = -32768;
+          }
+      }
+#pragma unroll
+      for (int c = 0; c < HM_QT; ++c) best[c] = max(best[c], tile_best(acc[c], tb));
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < HM_QT; ++c) {
+    const int b2 = max(best[c], __shfl_xor(best[c], 32));
+    const int q = q0 + 32 * c;
+    if (h == 0 && q < max_kp) {
+      int bidx = -1, bd = 512;
+      const int dot = b2 >> 16;
+      if (q < nq && nt > 0 && dot >= -256) {
+        bd = (256 - dot) >> 1;
+        bidx = 0xFFFF - (b2 & 0xFFFF);
+        if (bd > max_dist) bidx = -1;
+      }
+      idx_out[(size_t)p * max_kp + q] = bidx;
+      dist_out[(size_t)p * max_kp + q] = bd;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
 // optional scale pyramid: bilinear resize (11-bit weights, pixel-centre alignment) and the
 // level-major merge of per-level keypoints (include/vus.h)
 // all quantities fit 32 bits for images up to 2^24 pixels: num < 2 Ns Nd, rem * 2048 < 2^12 Nd
@@ -1114,6 +1242,9 @@ extern "C" int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, 
     if (max_dy >= 0)
       hamming_match_kernel<true><<<grid, 256, 0, vus::as_stream(stream)>>>(
           desc, kp_keys, kp_count, max_kp, W, q_index, t_index, max_dy, min_disp, max_disp, max_dist, idx_out, dist_out);
+    else if (max_kp <= 65535)   // ungated: int8 GEMM formulation on the matrix cores
+      hamming_match_mfma_kernel<<<dim3((max_kp + HM_QWG - 1) / HM_QWG, n_pairs), 256, 0, vus::as_stream(stream)>>>(
+          reinterpret_cast<const uint32_t*>(desc), kp_count, max_kp, q_index, t_index, max_dist, idx_out, dist_out);
     else
       hamming_match_kernel<false><<<grid, 256, 0, vus::as_stream(stream)>>>(
           desc, kp_keys, kp_count, max_kp, W, q_index, t_index, max_dy, min_disp, max_disp, max_dist, idx_out, dist_out);
