@@ -543,12 +543,15 @@ __global__ __launch_bounds__(256) void orient_rbrief_kernel(
     pr.load(im, H, W, pitch, y, x, lane, al_img);
     pb.load(bl, H, W, W, y, x, lane, al_blur);
   }
-  for (int it = 0; it < OR_KP_PER_WAVE; ++it) {   // uniform trip count: barriers are legal
+  __syncthreads();   // the weight tables are complete
+  // Each wave owns its two LDS patches: inside the loop only wave-level ordering is needed (LDS
+  // operations of one wave execute in order), so the four waves of a workgroup run unsynchronised.
+  for (int it = 0; it < OR_KP_PER_WAVE; ++it) {
     if (live) {
       pr.store(s_raw[wave], lane);
       pb.store(s_blur[wave], lane);
     }
-    __syncthreads();   // also orders the weight tables before their first use
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     const int ci = i, cx = x;
     const bool clive = live;
     if (it + 1 < OR_KP_PER_WAVE) {
@@ -579,16 +582,16 @@ __global__ __launch_bounds__(256) void orient_rbrief_kernel(
       const int m01 = wave_sum_i32(sy);
       const int m10 = sx - OR_R * si;
       // nearest bin direction = largest projection, first maximum wins (integer, exact)
-      long long prj = lane < VUS_N_ANGLE_BINS
-                          ? (long long)m10 * VUS_ANGLE_COS[lane] + (long long)m01 * VUS_ANGLE_SIN[lane]
+      // |prj| < 2^38, so (prj << 5) | (31 - bin) orders by projection, then by lowest bin, in one 64-bit max
+      long long key = lane < VUS_N_ANGLE_BINS
+                          ? ((long long)m10 * VUS_ANGLE_COS[lane] + (long long)m01 * VUS_ANGLE_SIN[lane]) * 32 + (31 - lane)
                           : (long long)(-0x7FFFFFFFFFFFFFFFll - 1);
-      int bin = lane;
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) {   // the 30 bins live in lanes 0..29: 32 lanes suffice
-        long long opr = __shfl_xor(prj, o);
-        int obin = __shfl_xor(bin, o);
-        if (opr > prj || (opr == prj && obin < bin)) { prj = opr; bin = obin; }
+        const long long ok = __shfl_xor(key, o);
+        key = ok > key ? ok : key;
       }
+      int bin = 31 - (int)(key & 31);
       bin = __builtin_amdgcn_readfirstlane(bin);
       const char4* pat = reinterpret_cast<const char4*>(VUS_RBRIEF_ROT) + (size_t)bin * 256;
       const uint8_t* c = blur8 + BR_R * (4 * BR_DW) + BR_R + sh_blur;   // the keypoint inside the patch
@@ -610,7 +613,7 @@ __global__ __launch_bounds__(256) void orient_rbrief_kernel(
       if (lane < 4) d[lane] = 0;
       if (lane == 0) angle_out[(size_t)n * max_kp + ci] = 0;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the patch is read before the next store overwrites it
   }
 }
 
@@ -900,7 +903,10 @@ TileGrid tile_grid(int n_img, int H, int W) {
 // lowest train index -- the brute-force result, bit for bit.
 typedef int v4i_t __attribute__((ext_vector_type(4)));
 typedef int v16i_t __attribute__((ext_vector_type(16)));
-constexpr int HM_CHUNK = 128;        // trains expanded per LDS chunk
+#ifndef VUS_HM_CHUNK
+#define VUS_HM_CHUNK 128
+#endif
+constexpr int HM_CHUNK = VUS_HM_CHUNK;        // trains expanded per LDS chunk
 constexpr int HM_ROWB = 272;         // bytes per expanded row: 256 + 16 (bank spread of the b128 reads)
 
 // 4 descriptor bits -> 4 bytes of +1 (bit set) / -1
@@ -909,7 +915,10 @@ __device__ __forceinline__ int spread_pm1(uint32_t nib) {
   return (int)~(sp * 0xFEu);
 }
 
-constexpr int HM_QT = 2;             // 32-query column tiles per wave (A fragments and the chunk expansion are shared)
+#ifndef VUS_HM_QT
+#define VUS_HM_QT 2
+#endif
+constexpr int HM_QT = VUS_HM_QT;             // 32-query column tiles per wave (A fragments and the chunk expansion are shared)
 constexpr int HM_QWG = 4 * 32 * HM_QT;   // queries per workgroup
 
 // best key of one 32x32 tile for this lane's query: per value (dot << 5) | (31 - row) with the row as an
