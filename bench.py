@@ -194,10 +194,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(a.warmup):
+    # set-up pass (not a step): loads the code objects, validates that no image overflowed the candidate
+    # buffer, and lets the clocks settle -- the first ~10 launches after an idle period run ~10 % slow
+    for _ in range(8):
         fe.process(images, check=False)
     barrier()
     fe.check_overflow()
+    for _ in range(a.warmup):
+        fe.process(images, check=False)
+    barrier()
     events = []
     barrier()
     t0 = time.perf_counter()
