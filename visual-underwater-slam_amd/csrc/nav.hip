@@ -265,62 +265,77 @@ __device__ __forceinline__ void imu_col(int c, int i, int j, int& node, int& dim
 
 // One workgroup adds the factors' J^T J / J^T r one factor after the other (fixed order => reproducible).
 // Thread t < 576 owns entry (c1, c2) of the 24x24 block, threads 576..599 the gradient entries.
-__global__ __launch_bounds__(640) void nav_accumulate_kernel(vus_nav_factors N, const double* __restrict__ rec_imu,
-                                                             const double* __restrict__ rec_dvl,
-                                                             double* __restrict__ Snav, double* __restrict__ Scb,
-                                                             double* __restrict__ Sbb, double* __restrict__ gnav,
-                                                             double* __restrict__ gb) {
-  const int t = threadIdx.x;
-  for (int f = 0; f < N.n_imu; ++f) {
-    const int i = N.imu_i[f], j = N.imu_j[f];
-    const double* R = rec_imu + IMU_REC * (size_t)f;
-    if (t < 576) {
-      const int c1 = t / 24, c2 = t - 24 * c1;
-      double h = 0.0;
+// One workgroup per factor.  A camera-side block receives at most two IMU factors, one DVL factor and
+// one velocity prior, so these go in with f64 atomics; the bias-bias block and the bias gradient, which
+// EVERY IMU factor touches, are written per factor and reduced in a fixed order afterwards.
+constexpr int NAV_BIAS_PART = 42;   // 36 (Sbb) + 6 (gb) per IMU factor
+__global__ __launch_bounds__(640) void nav_accumulate_imu_kernel(vus_nav_factors N, const double* __restrict__ rec_imu,
+                                                                 double* __restrict__ Snav, double* __restrict__ Scb,
+                                                                 double* __restrict__ gnav,
+                                                                 double* __restrict__ bias_part) {
+  const int t = threadIdx.x, f = blockIdx.x;
+  const int i = N.imu_i[f], j = N.imu_j[f];
+  const double* R = rec_imu + IMU_REC * (size_t)f;
+  if (t < 576) {
+    const int c1 = t / 24, c2 = t - 24 * c1;
+    double h = 0.0;
 #pragma unroll
-      for (int a = 0; a < 9; ++a) h += R[25 * a + c1] * R[25 * a + c2];
-      int n1, d1, n2, d2;
-      imu_col(c1, i, j, n1, d1);
-      imu_col(c2, i, j, n2, d2);
-      if (n1 >= 0 && n2 >= 0) {
-        if (n1 >= n2 && n1 - n2 <= 3) Snav[36 * ((size_t)n1 * 4 + (n1 - n2)) + 6 * d1 + d2] += h;
-      } else if (n1 >= 0 && n2 < 0) {
-        Scb[36 * (size_t)n1 + 6 * d1 + d2] += h;
-      } else if (n1 < 0 && n2 < 0) {
-        Sbb[6 * d1 + d2] += h;
-      }
-    } else if (t < 600) {
-      const int c = t - 576;
-      double gsum = 0.0;
-#pragma unroll
-      for (int a = 0; a < 9; ++a) gsum += R[25 * a + c] * R[25 * a + 24];
-      int n1, d1;
-      imu_col(c, i, j, n1, d1);
-      if (n1 >= 0) gnav[6 * (size_t)n1 + d1] += gsum;
-      else gb[d1] += gsum;
+    for (int a = 0; a < 9; ++a) h += R[25 * a + c1] * R[25 * a + c2];
+    int n1, d1, n2, d2;
+    imu_col(c1, i, j, n1, d1);
+    imu_col(c2, i, j, n2, d2);
+    if (n1 >= 0 && n2 >= 0) {
+      if (n1 >= n2 && n1 - n2 <= 3) unsafeAtomicAdd(&Snav[36 * ((size_t)n1 * 4 + (n1 - n2)) + 6 * d1 + d2], h);
+    } else if (n1 >= 0 && n2 < 0) {
+      unsafeAtomicAdd(&Scb[36 * (size_t)n1 + 6 * d1 + d2], h);
+    } else if (n1 < 0 && n2 < 0) {
+      bias_part[NAV_BIAS_PART * (size_t)f + 6 * d1 + d2] = h;
     }
-    __syncthreads();
+  } else if (t < 600) {
+    const int c = t - 576;
+    double gsum = 0.0;
+#pragma unroll
+    for (int a = 0; a < 9; ++a) gsum += R[25 * a + c] * R[25 * a + 24];
+    int n1, d1;
+    imu_col(c, i, j, n1, d1);
+    if (n1 >= 0) unsafeAtomicAdd(&gnav[6 * (size_t)n1 + d1], gsum);
+    else bias_part[NAV_BIAS_PART * (size_t)f + 36 + d1] = gsum;
   }
-  for (int f = 0; f < N.n_dvl; ++f) {
-    const int i = N.dvl_pose[f];
-    const double* R = rec_dvl + DVL_REC * (size_t)f;
-    if (t < 81) {
-      const int c1 = t / 9, c2 = t - 9 * c1;
-      double h = 0.0;
+}
+
+__global__ __launch_bounds__(64) void nav_bias_reduce_kernel(int n_imu, const double* __restrict__ bias_part,
+                                                            double* __restrict__ Sbb, double* __restrict__ gb) {
+  const int e = blockIdx.x, lane = threadIdx.x;
+  double acc = 0.0;
+  for (int f = lane; f < n_imu; f += 64) acc += bias_part[NAV_BIAS_PART * (size_t)f + e];
 #pragma unroll
-      for (int a = 0; a < 3; ++a) h += R[10 * a + c1] * R[10 * a + c2];
-      const int n1 = c1 < 6 ? 2 * i : 2 * i + 1, d1 = c1 < 6 ? c1 : c1 - 6;
-      const int n2 = c2 < 6 ? 2 * i : 2 * i + 1, d2 = c2 < 6 ? c2 : c2 - 6;
-      if (n1 >= n2) Snav[36 * ((size_t)n1 * 4 + (n1 - n2)) + 6 * d1 + d2] += h;
-    } else if (t < 90) {
-      const int c = t - 81;
-      double gsum = 0.0;
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (lane == 0) {
+    if (e < 36) Sbb[e] = acc;
+    else gb[e - 36] = acc;
+  }
+}
+
+__global__ __launch_bounds__(128) void nav_accumulate_dvl_kernel(vus_nav_factors N, const double* __restrict__ rec_dvl,
+                                                                 double* __restrict__ Snav, double* __restrict__ gnav) {
+  const int t = threadIdx.x, f = blockIdx.x;
+  const int i = N.dvl_pose[f];
+  const double* R = rec_dvl + DVL_REC * (size_t)f;
+  if (t < 81) {
+    const int c1 = t / 9, c2 = t - 9 * c1;
+    double h = 0.0;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) gsum += R[10 * a + c] * R[10 * a + 9];
-      const int n1 = c < 6 ? 2 * i : 2 * i + 1, d1 = c < 6 ? c : c - 6;
-      gnav[6 * (size_t)n1 + d1] += gsum;
-    }
-    __syncthreads();
+    for (int a = 0; a < 3; ++a) h += R[10 * a + c1] * R[10 * a + c2];
+    const int n1 = c1 < 6 ? 2 * i : 2 * i + 1, d1 = c1 < 6 ? c1 : c1 - 6;
+    const int n2 = c2 < 6 ? 2 * i : 2 * i + 1, d2 = c2 < 6 ? c2 : c2 - 6;
+    if (n1 >= n2) unsafeAtomicAdd(&Snav[36 * ((size_t)n1 * 4 + (n1 - n2)) + 6 * d1 + d2], h);
+  } else if (t < 90) {
+    const int c = t - 81;
+    double gsum = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) gsum += R[10 * a + c] * R[10 * a + 9];
+    const int n1 = c < 6 ? 2 * i : 2 * i + 1, d1 = c < 6 ? c : c - 6;
+    unsafeAtomicAdd(&gnav[6 * (size_t)n1 + d1], gsum);
   }
 }
 
@@ -477,10 +492,11 @@ int nav_errors(const vus_nav_factors* N, int n_poses, const double* poses, const
 
 }  // namespace
 
-// work layout: [records of the IMU factors | records of the DVL factors | error partials]
+// work layout: [records of the IMU factors | records of the DVL factors | error partials | bias partials]
 extern "C" long long vus_nav_work_doubles(const vus_nav_factors* N) {
   if (!N) return 0;
-  return (long long)IMU_REC * N->n_imu + (long long)DVL_REC * N->n_dvl + N->n_imu + N->n_dvl + N->n_vprior + 8;
+  return (long long)IMU_REC * N->n_imu + (long long)DVL_REC * N->n_dvl + N->n_imu + N->n_dvl + N->n_vprior + 8 +
+         (long long)NAV_BIAS_PART * N->n_imu;
 }
 
 extern "C" int vus_nav_linearize(const vus_nav_factors* N, int n_poses, const double* poses, const double* vels,
@@ -499,7 +515,12 @@ extern "C" int vus_nav_linearize(const vus_nav_factors* N, int n_poses, const do
   double* rec_dvl = rec_imu + (size_t)IMU_REC * N->n_imu;
   double* part = rec_dvl + (size_t)DVL_REC * N->n_dvl;
   if (int rc = nav_errors(N, n_poses, poses, vels, bias, nullptr, nullptr, 0, rec_imu, rec_dvl, part, err, st)) return rc;
-  nav_accumulate_kernel<<<1, 640, 0, st>>>(*N, rec_imu, rec_dvl, Snav, Scb, Sbb, gnav, gb);
+  double* bias_part = part + N->n_imu + N->n_dvl + N->n_vprior + 8;
+  if (N->n_imu > 0) {
+    nav_accumulate_imu_kernel<<<N->n_imu, 640, 0, st>>>(*N, rec_imu, Snav, Scb, gnav, bias_part);
+    nav_bias_reduce_kernel<<<NAV_BIAS_PART, 64, 0, st>>>(N->n_imu, bias_part, Sbb, gb);
+  }
+  if (N->n_dvl > 0) nav_accumulate_dvl_kernel<<<N->n_dvl, 128, 0, st>>>(*N, rec_dvl, Snav, gnav);
   nav_vprior_accumulate_kernel<<<1, 64, 0, st>>>(*N, vels, Snav, gnav);
   VUS_CHECK_LAUNCH("nav_linearize");
   return VUS_OK;
