@@ -269,6 +269,8 @@ def main():
             out["ba"] = ba_bench.run(device)
             # the reference's complete graph (stereo + IMU + DVL + priors) at its own plumbing size, configs[0]
             out["ba"]["full_graph_configs0"] = ba_bench.run_full_graph(device, 50, 500, 100)
+            # ... and the same complete graph at the configs[2] keyframe count
+            out["ba"]["full_graph_configs2"] = ba_bench.run_full_graph(device, 2000, 50000, 1000)
             if not a.no_cpu_baseline:
                 out["ba"]["cpu_baseline"] = ba_cpu_baseline(device)
         print(json.dumps(out), flush=True)
