@@ -474,7 +474,10 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 
 __device__ const uint8_t kDiscUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
-__global__ __launch_bounds__(256) void orient_rbrief_kernel(
+#ifndef VUS_OR_WPE
+#define VUS_OR_WPE 4
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE, 8))) void orient_rbrief_kernel(
     const uint8_t* __restrict__ img, const uint8_t* __restrict__ blur, int H, int W, int pitch,
     const uint32_t* __restrict__ kp_keys, const int* __restrict__ kp_count, int max_kp,
     uint64_t* __restrict__ desc_out, uint8_t* __restrict__ angle_out, int n_img, int chunks_per_img) {
