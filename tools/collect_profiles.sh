@@ -10,15 +10,19 @@ cd /tmp && export TMPDIR=/tmp
 # 1. plain bench line (no profiler attached)
 python3 $ROOT/bench.py > $OUT/bench_${TAG}.json 2> $OUT/bench_${TAG}.err || true
 # 2. rocprofv3 kernel trace + stats of the same command
-rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 $ROOT/bench.py > $OUT/bench_${TAG}_under_rocprof.json 2>/dev/null || true
+# (single-level headline only: the extra pyramid measurement launches the same kernels at 8 sizes and would blur the averages)
+rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 $ROOT/bench.py --no-pyramid > $OUT/bench_${TAG}_under_rocprof.json 2>/dev/null || true
 python3 $ROOT/tools/summarize_stats.py /tmp/prof_kt 40 | grep -v "at::native\|rocprim\|rocclr\|compute_cuda" > $OUT/kernel_stats_${TAG}.txt || true
 # 3. PMC passes (front-end kernels, 200 frames; separate passes as the guide prescribes)
-pmc() { name=$1; shift; rm -rf /tmp/pmc_$name; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -- python3 $ROOT/bench.py --frames 200 --steps 2 --warmup 1 --no-cpu-baseline --no-ba > /dev/null 2>&1 || true; }
+pmc() { name=$1; shift; rm -rf /tmp/pmc_$name; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -- python3 $ROOT/bench.py --frames 200 --steps 2 --warmup 1 --no-cpu-baseline --no-ba --no-pyramid > /dev/null 2>&1 || true; }
 pmc sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR
 pmc sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 python3 $ROOT/tools/summarize_pmc.py /tmp/pmc_sq1 /tmp/pmc_sq2 /tmp/pmc_fetch /tmp/pmc_write --traffic-json $OUT/traffic.json 400 > $OUT/pmc_frontend_${TAG}.txt || true
+# 3b. the 8-level pyramid mode (500 frames, 3 passes)
+rm -rf /tmp/prof_py && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_py -- python3 $ROOT/tools/pyramid_profile.py 500 > /dev/null 2>&1 || true
+python3 $ROOT/tools/summarize_stats.py /tmp/prof_py 40 | grep -v "at::native\|rocprim\|rocclr\|compute_cuda" > $OUT/kernel_stats_pyramid_${TAG}.txt || true
 # 4. BA kernels: stats + MFMA counters
 rm -rf /tmp/prof_ba && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ba -- python3 $ROOT/tools/ba_profile.py > /dev/null 2>&1 || true
 python3 $ROOT/tools/summarize_stats.py /tmp/prof_ba 40 | grep -v "at::native\|rocprim\|rocclr\|compute_cuda" > $OUT/kernel_stats_ba_${TAG}.txt || true
