@@ -223,6 +223,47 @@ def test_hamming_match_bit_exact(gpu, oracle, gate):
         assert (edist[4, :kc[1]] == 0).all()
 
 
+@pytest.mark.parametrize("max_dist", [256, 40])
+def test_ungated_matcher_edge_cases_random_descriptors(gpu, oracle, max_dist):
+    """The matrix-core matcher on synthetic descriptor sets: duplicates (ties -> lowest index), all-zero and
+    all-one descriptors, counts that are 0 / 1 / not multiples of the 32-row tiles, fewer trains than queries."""
+    import visual_underwater_slam_amd._lib as L
+    rng = np.random.default_rng(11)
+    K, n_img = 300, 6
+    desc = rng.integers(0, 2**63, size=(n_img, K, 4), dtype=np.int64).view(np.uint64)
+    desc ^= rng.integers(0, 2, size=desc.shape, dtype=np.uint64) << np.uint64(63)
+    desc[1, 5] = desc[1, 2]                      # duplicates inside a train set: the lower index must win
+    desc[1, 200] = desc[1, 2]
+    desc[0, 7] = desc[1, 2]
+    desc[0, 8] = 0
+    desc[0, 9] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    desc[1, 33] = 0
+    desc[1, 64] = np.uint64(0xFFFFFFFFFFFFFFFF)
+    desc[2, :, :] = desc[0, :, :]                # image 2 == image 0 except for bit flips of growing weight
+    for i in range(K):
+        w = rng.integers(0, 256, size=i % 60)
+        for b in w:
+            desc[2, i, b // 64] ^= np.uint64(1) << np.uint64(b % 64)
+    kc = np.array([300, 257, 300, 1, 0, 33], np.int32)
+    kp = np.zeros((n_img, K), np.uint32)          # positions are not used by the ungated matcher
+    q = np.array([0, 1, 0, 0, 0, 5, 3, 4, 2], np.int32)
+    t = np.array([1, 0, 2, 3, 4, 1, 0, 0, 0], np.int32)
+    eidx, edist = oracle.hamming_match(desc, kp, kc, 64, q, t, -1, 0, 0, max_dist, H=64)
+    idx = torch.empty((len(q), K), dtype=torch.int32, device="cuda")
+    dist = torch.empty((len(q), K), dtype=torch.int32, device="cuda")
+    L.call("vus_hamming_match", _dev(desc.view(np.int64)).data_ptr(), _dev(kp.view(np.int32)).data_ptr(),
+           _dev(kc).data_ptr(), K, 64, 64, _dev(q).data_ptr(), _dev(t).data_ptr(), len(q), -1, 0, 0, max_dist,
+           idx.data_ptr(), dist.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.cpu().numpy(), eidx)
+    assert np.array_equal(dist.cpu().numpy(), edist)
+    assert eidx[0, 7] == 2 and edist[0, 7] == 0                      # three identical trains: index 2 wins
+    assert (eidx[4] == -1).all() and (edist[4] == 512).all()         # empty train set
+    assert (eidx[7] == -1).all()                                     # empty query set
+    if max_dist == 256:
+        assert (eidx[3, :300] == 0).all()                            # single train descriptor
+
+
 def test_triangulate_matches_oracle(gpu, oracle):
     from visual_underwater_slam_amd import frontend
     rng = np.random.default_rng(8)
