@@ -407,10 +407,15 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
 // image for the centroid disc, 37 rows of the smoothed image for the tests), then gathers from LDS.
 constexpr int OR_R = 15;                    // disc radius
 constexpr int OR_ROWS = 2 * OR_R + 1;       // 31
-constexpr int OR_DW = 9;                    // 36 bytes cover x-15..x+15 from an aligned start
+#ifndef VUS_OR_VW
+#define VUS_OR_VW 2
+#endif
+constexpr int OR_VW = VUS_OR_VW;               // dwords per lane and load
+constexpr int OR_DW = OR_VW == 4 ? 12 : 10;    // 36 bytes cover x-15..x+15 from an aligned start; a multiple of OR_VW is loaded
+constexpr int OR_MW = 10;                   // dword columns that can hold disc pixels
 constexpr int BR_R = VUS_RBRIEF_REACH;      // 18
 constexpr int BR_ROWS = 2 * BR_R + 1;       // 37
-constexpr int BR_DW = 10;                   // 40 bytes cover x-18..x+18 from an aligned start
+constexpr int BR_DW = OR_VW == 4 ? 12 : 10;    // 40 bytes cover x-18..x+18 from an aligned start
 #ifndef VUS_OR_KPW
 #define VUS_OR_KPW 8
 #endif
@@ -418,19 +423,29 @@ constexpr int OR_KP_PER_WAVE = VUS_OR_KPW;  // keypoints handled sequentially by
 
 // Load a (2*RADIUS+1) x (4*DW)-byte patch around (x, y) into registers: every lane issues all of
 // its dword loads back to back (one memory round trip), the caller stores them to LDS afterwards.
-template <int RADIUS, int DW>
+// A lane moves VW dwords (dwordx2 / dwordx4 access at dword alignment): the texture path's cost is per
+// instruction, not per byte -- 11 dword loads per keypoint took 3.19 ms per 1000 frames, 6 dwordx2 2.82
+// (4 dwordx4 of 48-byte rows: 3.04).
+template <int VW> struct PatchVec;
+template <> struct PatchVec<2> { typedef uint32_t type __attribute__((ext_vector_type(2), aligned(4))); };
+template <> struct PatchVec<4> { typedef uint32_t type __attribute__((ext_vector_type(4), aligned(4))); };
+
+template <int RADIUS, int DW, int VW>
 struct PatchRegs {
+  static_assert(DW % VW == 0, "row width must be a multiple of the vector width");
+  typedef typename PatchVec<VW>::type vec_t;
   static constexpr int ROWS = 2 * RADIUS + 1;
-  static constexpr int N = ROWS * DW;
+  static constexpr int HW = DW / VW;            // vectors per row
+  static constexpr int N = ROWS * HW;
   static constexpr int ITERS = (N + 63) / 64;
-  uint32_t v[ITERS];
-  int off[ITERS];   // byte offset of this lane's dwords inside an in-image patch (fixed per kernel)
+  vec_t v[ITERS];
+  int off[ITERS];   // byte offset of this lane's vectors inside an in-image patch (fixed per kernel)
 
   __device__ __forceinline__ void init(int pitch, int lane) {
 #pragma unroll
     for (int u = 0; u < ITERS; ++u) {
       const int t = min(lane + 64 * u, N - 1);
-      off[u] = (t / DW) * pitch + 4 * (t % DW);
+      off[u] = (t / HW) * pitch + 4 * VW * (t % HW);
     }
   }
   __device__ __forceinline__ void load(const uint8_t* __restrict__ src, int H, int W, int pitch, int y, int x,
@@ -440,23 +455,30 @@ struct PatchRegs {
     if (inside) {   // wave-uniform
       const uint8_t* base = src + (size_t)(y - RADIUS) * pitch + xa;
 #pragma unroll
-      for (int u = 0; u < ITERS; ++u) v[u] = *reinterpret_cast<const uint32_t*>(base + off[u]);
+      for (int u = 0; u < ITERS; ++u) v[u] = *reinterpret_cast<const vec_t*>(base + off[u]);
     } else {        // replicate-clamped, byte by byte (keypoints near the image edge)
 #pragma unroll
       for (int u = 0; u < ITERS; ++u) {
         const int t = min(lane + 64 * u, N - 1);
-        const int r = t / DW, c = t - r * DW;
+        const int r = t / HW, c = t - r * HW;
         const uint8_t* rp = src + (size_t)clampi(y - RADIUS + r, 0, H - 1) * pitch;
-        const int gx = xa + 4 * c;
-        v[u] = (uint32_t)rp[clampi(gx, 0, W - 1)] | ((uint32_t)rp[clampi(gx + 1, 0, W - 1)] << 8) |
-               ((uint32_t)rp[clampi(gx + 2, 0, W - 1)] << 16) | ((uint32_t)rp[clampi(gx + 3, 0, W - 1)] << 24);
+        const int gx = xa + 4 * VW * c;
+#pragma unroll
+        for (int k = 0; k < VW; ++k)
+          v[u][k] = (uint32_t)rp[clampi(gx + 4 * k, 0, W - 1)] | ((uint32_t)rp[clampi(gx + 4 * k + 1, 0, W - 1)] << 8) |
+                    ((uint32_t)rp[clampi(gx + 4 * k + 2, 0, W - 1)] << 16) |
+                    ((uint32_t)rp[clampi(gx + 4 * k + 3, 0, W - 1)] << 24);
       }
     }
   }
   __device__ __forceinline__ void store(uint32_t* __restrict__ dst, int lane) const {
 #pragma unroll
     for (int u = 0; u < ITERS; ++u)
-      if (lane + 64 * u < N) dst[lane + 64 * u] = v[u];
+      if (lane + 64 * u < N) {
+        uint32_t* d = dst + VW * (lane + 64 * u);
+#pragma unroll
+        for (int k = 0; k < VW; k += 2) *reinterpret_cast<uint2*>(d + k) = make_uint2(v[u][k], v[u][k + 1]);
+      }
   }
 };
 
@@ -481,12 +503,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
     const uint8_t* __restrict__ img, const uint8_t* __restrict__ blur, int H, int W, int pitch,
     const uint32_t* __restrict__ kp_keys, const int* __restrict__ kp_count, int max_kp,
     uint64_t* __restrict__ desc_out, uint8_t* __restrict__ angle_out, int n_img, int chunks_per_img) {
-  __shared__ uint32_t s_raw[4][OR_ROWS * OR_DW];
-  __shared__ uint32_t s_blur[4][BR_ROWS * BR_DW];
+  __shared__ __attribute__((aligned(8))) uint32_t s_raw[4][OR_ROWS * OR_DW];
+  __shared__ __attribute__((aligned(8))) uint32_t s_blur[4][BR_ROWS * BR_DW];
   // centroid weights per patch dword, for the 4 possible byte alignments of the patch:
   // s_wx = (dx + 15) inside the disc else 0 (u8 x 4), s_wm = 1 inside the disc else 0
-  __shared__ uint32_t s_wx[4 * OR_ROWS * OR_DW];
-  __shared__ uint32_t s_wm[4 * OR_ROWS * OR_DW];
+  __shared__ uint32_t s_wx[4 * OR_ROWS * OR_MW];
+  __shared__ uint32_t s_wm[4 * OR_ROWS * OR_MW];
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   // XCD-aware block -> (image, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so all
@@ -496,9 +518,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
   const int n = (slot / chunks_per_img) * 8 + xcd;
   const int chunk = slot - (slot / chunks_per_img) * chunks_per_img;
   if (n >= n_img) return;
-  for (int e = threadIdx.x; e < 4 * OR_ROWS * OR_DW; e += 256) {
-    const int sh = e / (OR_ROWS * OR_DW), t = e - sh * (OR_ROWS * OR_DW);
-    const int r = t / OR_DW, c = t - r * OR_DW;
+  for (int e = threadIdx.x; e < 4 * OR_ROWS * OR_MW; e += 256) {
+    const int sh = e / (OR_ROWS * OR_MW), t = e - sh * (OR_ROWS * OR_MW);
+    const int r = t / OR_MW, c = t - r * OR_MW;
     const int dy = r - OR_R, um = kDiscUmax[dy < 0 ? -dy : dy];
     uint32_t wx = 0, wm = 0;
 #pragma unroll
@@ -519,10 +541,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
   const int count = kp_count[n];
   const uint8_t* blur8 = reinterpret_cast<const uint8_t*>(s_blur[wave]);
   // this lane's share of the centroid patch: row offsets dy of its dwords
-  constexpr int MOM_ITERS = (OR_ROWS * OR_DW + 63) / 64;
-  int mom_dy[MOM_ITERS];
+  constexpr int MOM_ITERS = (OR_ROWS * OR_MW + 63) / 64;   // the disc lives in the first OR_MW dword columns
+  int mom_dy[MOM_ITERS], mom_idx[MOM_ITERS];
 #pragma unroll
-  for (int u = 0; u < MOM_ITERS; ++u) mom_dy[u] = min(lane + 64 * u, OR_ROWS * OR_DW - 1) / OR_DW - OR_R;
+  for (int u = 0; u < MOM_ITERS; ++u) {
+    const int t = min(lane + 64 * u, OR_ROWS * OR_MW - 1);
+    mom_dy[u] = t / OR_MW - OR_R;
+    mom_idx[u] = (t / OR_MW) * OR_DW + t % OR_MW;
+  }
   // software pipeline over this wave's keypoints: the patch loads of keypoint it+1 are in flight
   // while keypoint it is reduced out of LDS
   auto kp_xy = [&](int it, int& i, bool& live, int& y, int& x) {
@@ -535,8 +561,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
       x = (int)(pos - (uint32_t)y * (uint32_t)W);
     }
   };
-  PatchRegs<OR_R, OR_DW> pr;
-  PatchRegs<BR_R, BR_DW> pb;
+  PatchRegs<OR_R, OR_DW, OR_VW> pr;
+  PatchRegs<BR_R, BR_DW, OR_VW> pb;
   pr.init(pitch, lane);
   pb.init(W, lane);
   int i, y, x;
@@ -571,9 +597,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
 #pragma unroll
       for (int u = 0; u < MOM_ITERS; ++u) {
         const int t = lane + 64 * u;
-        if (t < OR_ROWS * OR_DW) {
-          const uint32_t v = s_raw[wave][t];
-          const int e = sh_raw * (OR_ROWS * OR_DW) + t;
+        if (t < OR_ROWS * OR_MW) {
+          const uint32_t v = s_raw[wave][mom_idx[u]];
+          const int e = sh_raw * (OR_ROWS * OR_MW) + t;
           sx = (int)__builtin_amdgcn_udot4(v, s_wx[e], (uint32_t)sx, false);
           const int rs = (int)__builtin_amdgcn_udot4(v, s_wm[e], 0u, false);
           si += rs;
