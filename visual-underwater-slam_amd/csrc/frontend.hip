@@ -496,6 +496,18 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 
 __device__ const uint8_t kDiscUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
+// Rotated test pattern re-laid for the kernel: [bin][lane][word] = the two patch byte offsets
+// (y * row bytes + x, int16 each) of test 64 * word + lane.  Filled once per device from VUS_RBRIEF_ROT.
+__device__ __attribute__((aligned(16))) uint32_t g_rot_off[VUS_N_ANGLE_BINS * 64 * 4];
+__global__ void rot_table_init_kernel() {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= VUS_N_ANGLE_BINS * 256) return;
+  const int bin = e / 256, test = e - 256 * bin, w = test >> 6, lane = test & 63;
+  const int8_t* t = VUS_RBRIEF_ROT + 4 * (size_t)e;
+  const int oa = t[1] * (4 * BR_DW) + t[0], ob = t[3] * (4 * BR_DW) + t[2];
+  g_rot_off[(bin * 64 + lane) * 4 + w] = ((uint32_t)oa & 0xFFFFu) | ((uint32_t)ob << 16);
+}
+
 #ifndef VUS_OR_WPE
 #define VUS_OR_WPE 4
 #endif
@@ -622,14 +634,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
       }
       int bin = 31 - (int)(key & 31);
       bin = __builtin_amdgcn_readfirstlane(bin);
-      const char4* pat = reinterpret_cast<const char4*>(VUS_RBRIEF_ROT) + (size_t)bin * 256;
+      // this lane's four tests of the bin's pattern, as patch byte offsets: one 16-byte load
+      const uint4 to = reinterpret_cast<const uint4*>(g_rot_off)[bin * 64 + lane];
       const uint8_t* c = blur8 + BR_R * (4 * BR_DW) + BR_R + sh_blur;   // the keypoint inside the patch
+      const uint32_t tw[4] = {to.x, to.y, to.z, to.w};
       uint64_t word[4];
 #pragma unroll
       for (int w = 0; w < 4; ++w) {
-        const char4 t = pat[w * 64 + lane];
-        const int a = c[t.y * (4 * BR_DW) + t.x];
-        const int b = c[t.w * (4 * BR_DW) + t.z];
+        const int a = c[(int16_t)(tw[w] & 0xFFFFu)];
+        const int b = c[(int16_t)(tw[w] >> 16)];
         word[w] = __ballot(a < b);  // lane l supplies bit l of word w
       }
       if (lane == 0) {
@@ -1252,6 +1265,17 @@ extern "C" int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_
   const int chunks = (max_kp + 4 * OR_KP_PER_WAVE - 1) / (4 * OR_KP_PER_WAVE);
   const long long blocks = (long long)((n_img + 7) / 8) * 8 * chunks;
   VUS_REQUIRE(blocks < (1ll << 31), "too many workgroups (%lld)", blocks);
+  {
+    static bool table_ready[64] = {};   // per device; a repeated initialisation writes the same values
+    int dev = 0;
+    VUS_CHECK_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !table_ready[dev]) {
+      rot_table_init_kernel<<<(VUS_N_ANGLE_BINS * 256 + 255) / 256, 256, 0, vus::as_stream(stream)>>>();
+      table_ready[dev] = true;
+    } else if (dev < 0 || dev >= 64) {
+      rot_table_init_kernel<<<(VUS_N_ANGLE_BINS * 256 + 255) / 256, 256, 0, vus::as_stream(stream)>>>();
+    }
+  }
   orient_rbrief_kernel<<<(unsigned)blocks, 256, 0, vus::as_stream(stream)>>>(
       img, blur, H, W, pitch, kp_keys, kp_count, max_kp, desc_out, angle_out, n_img, chunks);
   VUS_CHECK_LAUNCH("orient_rbrief");
