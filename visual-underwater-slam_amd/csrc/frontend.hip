@@ -128,12 +128,11 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
   // stage the tile as dwords; out-of-image pixels replicate the border (what the smoothing wants;
   // FAST never produces a score within 3 pixels of the edge, so it does not care).
   // Thread = fixed dword column, 7 rows per pass: no per-element division, one address increment.
-  const bool al_in = ((reinterpret_cast<uintptr_t>(im) | (uintptr_t)pitch) & 3u) == 0;
   {
     constexpr int RPP = NTHREADS / IMG_DW;   // rows per pass
     const int col = tid % IMG_DW, r0 = tid / IMG_DW;
     const int gx = x0 - 8 + 4 * col;
-    const bool fast = al_in && gx >= 0 && gx + 3 < W;
+    const bool fast = gx >= 0 && gx + 3 < W;   // one dword load, aligned or not (odd-width pyramid levels)
     const int c0 = clampi(gx, 0, W - 1), c1 = clampi(gx + 1, 0, W - 1), c2 = clampi(gx + 2, 0, W - 1),
               c3 = clampi(gx + 3, 0, W - 1);
     if (r0 < RPP) {
@@ -143,7 +142,7 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
         if (row < IMG_ROWS) {
           const uint8_t* rp = im + (size_t)clampi(y0 - 4 + row, 0, H - 1) * pitch;
           uint32_t v;
-          if (fast) v = *reinterpret_cast<const uint32_t*>(rp + gx);
+          if (fast) __builtin_memcpy(&v, rp + gx, 4);
           else v = (uint32_t)rp[c0] | ((uint32_t)rp[c1] << 8) | ((uint32_t)rp[c2] << 16) | ((uint32_t)rp[c3] << 24);
           s_img[row * IMG_DW + col] = v;
         }
@@ -265,7 +264,6 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
   }
   if (BLUR) {
     constexpr int BW[7] = {18, 33, 49, 56, 49, 33, 18};
-    const bool al_out = ((reinterpret_cast<uintptr_t>(blur_out) | (uintptr_t)W) & 3u) == 0;
     for (int idx = tid; idx < TH * STRIPS; idx += NTHREADS) {
       const int ly = idx / STRIPS, ls = idx - ly * STRIPS;
       const int gy = y0 + ly, gx = x0 + 4 * ls;
@@ -282,8 +280,8 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
                          (((a3 + 32768u) >> 16) << 24);
       if (gy < H) {
         uint8_t* o = blur_out + ((size_t)n * H + gy) * W + gx;
-        if (al_out && gx + 3 < W) {
-          *reinterpret_cast<uint32_t*>(o) = v;
+        if (gx + 3 < W) {
+          __builtin_memcpy(o, &v, 4);
         } else {
 #pragma unroll
           for (int e = 0; e < 4; ++e)
