@@ -240,7 +240,9 @@ int vus_ba_add_diag(double* Sband, int n_poses, int band, double value, void* st
 
 /* Solve S dp = -gs by block-band Cholesky; n_poses counts NODES.  Sband is overwritten by the factor L in
  * the solver's own layout: the 6x6 blocks left of the 8-node diagonal panels hold their transposes.
- * status[0] = 0 ok, k+1 = non-positive pivot met in scalar column k (dp is then undefined). */
+ * status[0] = 0 ok, k+1 = non-positive pivot met in scalar column k (dp is then undefined), -1 = the
+ * cooperative back-substitution gave up waiting (never observed; the waits are bounded so that a scheduling
+ * anomaly cannot hang the GPU).  The sweep's flags live in the unused slots of block row 0 of Sband. */
 int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, double* dp,
                       int* status, void* stream);
 
