@@ -400,7 +400,9 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, i
   const int p0 = S.blk_ptr[q], p1 = S.blk_ptr[q + 1];
   // Four lanes per pair: lane (rh, ch) loads rows 3rh..3rh+2 of Y_a and 3ch..3ch+2 of W_b (9 contiguous
   // doubles each) and accumulates the 3x3 sub-block -- 576 B requested from the L1 per pair instead of
-  // 1152 B with 12 lanes per pair (the kernel is bound by L1 request bandwidth, not by HBM or latency).
+  // 1152 B with 12 lanes per pair (3.2 -> 2.0 ms at configs[2]).  Fewer lanes per pair do not help further
+  // (2 lanes: 2.07 ms, 1 lane: 2.6 ms, measured): 57.5 M pairs x 288 B of unique rows = 16.5 GB cross the L2 -> L1
+  // path in those 2 ms, about what that path sustains for a gather.
   const int sl = lane >> 2, rh = (lane >> 1) & 1, ch = lane & 1;
   typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte loads from 8-byte aligned rows
   double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
