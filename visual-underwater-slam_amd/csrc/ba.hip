@@ -448,6 +448,101 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, i
   }
 }
 
+// Row-resident variant of the block accumulation: one workgroup per pose i keeps that pose's Y rows (its
+// P-order segment, <= SR_ROWS x 144 B per chunk) in LDS while its waves walk the blocks (i, k) of the row,
+// so only the W rows travel L2 -> L1 per pair (144 B instead of 288 B).  Lane = 16 * (rh, ch) + pair slot: a
+// 16-lane DPP row holds one 3x3 sub-block position, and the sum over the 16 slots is four DPP row shifts
+// with no cross-row step.  Rows longer than SR_ROWS are processed in chunks (pair_a ascends inside a block,
+// so a chunk's pairs are a sub-range found by bisection).  Deterministic, no atomics.
+#ifndef VUS_SR_ROWS
+#define VUS_SR_ROWS 1000
+#endif
+#ifndef VUS_SR_THREADS
+#define VUS_SR_THREADS 1024
+#endif
+constexpr int SR_ROWS = VUS_SR_ROWS;
+constexpr int SR_THREADS = VUS_SR_THREADS;
+
+__device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int lo, int hi, int key) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1;
+    else hi = mid;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure S, const int* __restrict__ pose_ptr,
+                                                                int ps, const double* __restrict__ W,
+                                                                const double* __restrict__ Y,
+                                                                double* __restrict__ Sband) {
+  extern __shared__ double s_y[];          // [rows of the chunk][18]
+  __shared__ int s_b0, s_b1;
+  const int i = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) {
+    s_b0 = lower_bound_i32(S.blk_i, 0, S.n_blocks, i);
+    s_b1 = lower_bound_i32(S.blk_i, 0, S.n_blocks, i + 1);
+  }
+  const int a0 = pose_ptr[i], a1 = pose_ptr[i + 1];
+  __syncthreads();
+  const int b0 = s_b0, b1 = s_b1;
+  if (b0 == b1) return;
+  const int res = lane >> 4, sl = lane & 15, rh = res >> 1, ch = res & 1;
+  typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));
+  for (int c0 = a0; c0 < a1; c0 += SR_ROWS) {
+    const int c1 = min(c0 + SR_ROWS, a1);
+    if (c0 > a0) __syncthreads();    // the previous chunk has been consumed
+    {
+      const d2_t* src = reinterpret_cast<const d2_t*>(Y + 18 * (size_t)c0);
+      d2_t* dst = reinterpret_cast<d2_t*>(s_y);
+      for (int t = tid; t < 9 * (c1 - c0); t += SR_THREADS) dst[t] = src[t];
+    }
+    __syncthreads();
+    const bool whole = c0 == a0 && c1 == a1;
+    for (int q = b0 + wave; q < b1; q += SR_THREADS / 64) {
+      const int k = S.blk_k[q];
+      int p0 = S.blk_ptr[q], p1 = S.blk_ptr[q + 1];
+      if (!whole) {   // the pairs whose Y row lies in this chunk
+        p1 = lower_bound_i32(S.pair_a, p0, p1, c1);
+        p0 = lower_bound_i32(S.pair_a, p0, p1, c0);
+      }
+      if (p0 >= p1) continue;
+      double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+      for (int p = p0 + sl; p < p1; p += 16) {
+        const double* Ya = s_y + 18 * (S.pair_a[p] - c0) + 9 * rh;
+        const double* Wb = W + 18 * (size_t)S.pair_b[p] + 9 * ch;
+        double y[9], w[10];
+#pragma unroll
+        for (int h = 0; h < 9; ++h) y[h] = Ya[h];
+#pragma unroll
+        for (int h = 0; h < 4; ++h) {
+          const d2_t wv = *reinterpret_cast<const d2_t*>(Wb + 2 * h);
+          w[2 * h] = wv.x; w[2 * h + 1] = wv.y;
+        }
+        w[8] = Wb[8];
+#pragma unroll
+        for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+          for (int b2 = 0; b2 < 3; ++b2)
+            acc[a2][b2] += y[3 * a2] * w[3 * b2] + y[3 * a2 + 1] * w[3 * b2 + 1] + y[3 * a2 + 2] * w[3 * b2 + 2];
+      }
+      double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k)) + 6 * (3 * rh) + 3 * ch;
+#pragma unroll
+      for (int a2 = 0; a2 < 3; ++a2)
+#pragma unroll
+        for (int b2 = 0; b2 < 3; ++b2) {
+          double v = acc[a2][b2];
+          v += dpp_shr_f64<0x111>(v);   // row_shr:1
+          v += dpp_shr_f64<0x112>(v);   // row_shr:2
+          v += dpp_shr_f64<0x114>(v);   // row_shr:4
+          v += dpp_shr_f64<0x118>(v);   // row_shr:8  -> lane 15 of the row holds the sum over its 16 slots
+          if (sl == 15) blk[6 * a2 + b2] -= v;
+        }
+    }
+  }
+}
+
 // gs_i = gp_i - sum_{slots of pose i} Y_s gl[point(s)]   (one wave per pose)
 __global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const double* __restrict__ Y,
                                                        const double* __restrict__ gl,
@@ -1348,7 +1443,20 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
   if (nL > 0) vinv_kernel<<<cdiv(nL, 256), 256, 0, st>>>(nL, lambda, V, Vinv);
   if (nO > 0) ymul_kernel<<<cdiv(nO, 256), 256, 0, st>>>(*P, W, Vinv, Y);
   schur_init_kernel<<<cdiv(36ll * nP, 256), 256, 0, st>>>(nP, S->band, ps, lambda, Hpp, Sband);
-  if (S->n_blocks > 0) schur_blocks_kernel<<<cdiv(S->n_blocks, 4), 256, 0, st>>>(*S, ps, W, Y, Sband);
+  if (S->n_blocks > 0) {
+#ifdef VUS_SCHUR_BLOCKS
+    schur_blocks_kernel<<<cdiv(S->n_blocks, 4), 256, 0, st>>>(*S, ps, W, Y, Sband);
+#else
+    static bool lds_set = false;
+    constexpr int lds = SR_ROWS * 18 * (int)sizeof(double);
+    if (!lds_set) {
+      VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(schur_rows_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+      lds_set = true;
+    }
+    schur_rows_kernel<<<nP, SR_THREADS, lds, st>>>(*S, P->pose_ptr, ps, W, Y, Sband);
+#endif
+  }
   schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, Y, gl, gp, gs);
   VUS_CHECK_LAUNCH("ba_schur");
   return VUS_OK;
