@@ -29,7 +29,8 @@ def setup(oracle, n_kf, n_lm, obs, **kw):
     return s, prob, solver, P
 
 
-@pytest.mark.parametrize("size", [(12, 60, 30), (50, 500, 100), (150, 4000, 300)])
+# (8, 4000, 2500): ~2300 observations per pose, i.e. three chunks of the row-resident Schur kernel (1000 rows each)
+@pytest.mark.parametrize("size", [(12, 60, 30), (50, 500, 100), (150, 4000, 300), (8, 4000, 2500)])
 def test_kernels_match_oracle_stage_by_stage(gpu, oracle, size):
     s, prob, sv, P = setup(oracle, *size)
     poses = torch.from_numpy(s["poses_init"]).cuda()
