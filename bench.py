@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 
 H, W, KP = 720, 1280, 2000
+INT8_PEAK_TOPS = 5000.0   # dense int8 MFMA: 2x the ~2.5 PFLOP/s dense bf16 peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 # Algorithmic bytes (single pyramid level), per stereo frame:
@@ -238,6 +239,12 @@ def main():
                              "rate, profiles/valu_issue_rates_*.txt); traffic = FETCH_SIZE+WRITE_SIZE of a separate "
                              "rocprofv3 --pmc run (profiles/traffic.json), scaled to this launch"},
     }
+    # second bound, informational: the track matcher is an int8 GEMM on the matrix cores (2000 x 2000 x 256 multiply-
+    # accumulates per image pair = the algorithmic work of brute-force Hamming matching in its dot-product form)
+    mm_ops = 2.0 * (F - 1) * KP * KP * 256
+    out["roofline_matcher"] = {"kernel": "hamming_track", "bound": "mfma", "achieved": round(mm_ops / (stage_ms["hamming_track"] * 1e-3) / 1e12, 1),
+                               "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(mm_ops / (stage_ms["hamming_track"] * 1e-3) / 1e12 / INT8_PEAK_TOPS, 4),
+                               "note": "dense int8 MFMA peak = 2x the ~2.5 PFLOP/s bf16 peak (MI355X_MICROARCH.md, matrix cores)"}
     if rank == 0:
         if not a.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(a.cpu_frames, 0)
