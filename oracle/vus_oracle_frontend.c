@@ -15,8 +15,10 @@
  *     smoothed 31x31 patch: Rublee et al., "ORB", ICCV 2011, sec. 3.2 and 4.2.
  *   - brute-force Hamming matching with a row gate (stereo_threshold=5 = stereo.launch:47).
  *   - get_landmarks: batch.py:144-176 (this one IS in the reference and is followed verbatim).
- * The oracle is pinned only by the known-answer tests in tests/ (hand-built patches) and by
- * self-generated golden vectors under tests/golden/.
+ * The oracle is pinned only by the known-answer tests in tests/ (hand-built patches), by
+ * self-generated golden vectors under tests/golden/, and -- detector corner set and orientation bin
+ * only -- by agreement with scikit-image 0.18.3, an independent implementation of the same published
+ * algorithms (tests/test_thirdparty_crosscheck.py).
  *
  * Everything here is written for clarity, one pixel / one keypoint at a time.
  */
