@@ -16,6 +16,20 @@ from visual_underwater_slam_amd.gtsam.optimizer import _pack_graph
 from visual_underwater_slam_amd import synth
 
 
+def test_batch_py_import_lines_resolve():
+    """Every name batch.py:18-27 imports from gtsam exists in the shim (used or not)."""
+    import importlib
+    g = importlib.import_module("visual_underwater_slam_amd.gtsam")
+    for name in ["ISAM2", "BetweenFactorConstantBias", "Cal3_S2", "ConstantTwistScenario", "ImuFactor",
+                 "NonlinearFactorGraph", "PinholeCameraCal3_S2", "Point3", "Pose3", "PriorFactorConstantBias",
+                 "PriorFactorPose3", "PriorFactorVector", "Rot3", "Values", "PriorFactorPoint3", "NavState",
+                 "Cal3_S2Stereo", "StereoPoint2", "GenericStereoFactor3D"]:
+        assert hasattr(g, name), name
+    sh = importlib.import_module("visual_underwater_slam_amd.gtsam.symbol_shorthand")
+    assert all(hasattr(sh, n) for n in "BVXL")
+    importlib.import_module("visual_underwater_slam_amd.gtsam.utils").plot
+
+
 def test_symbol_keys():
     assert X(0) == ord("x") << 56 and L(7) == (ord("l") << 56) | 7
     assert gtsam.symbol_shorthand.symbolChr(V(3)) == "v" and gtsam.symbol_shorthand.symbolIndex(B(9)) == 9

@@ -30,7 +30,8 @@ __all__ = [
     "Point3", "Rot3", "Pose3", "Cal3_S2Stereo", "Cal3_S2", "StereoPoint2", "noiseModel", "imuBias",
     "GenericStereoFactor3D", "PriorFactorPose3", "PriorFactorVector", "PriorFactorPoint3",
     "PriorFactorConstantBias", "BetweenFactorConstantBias", "ImuFactor", "CustomFactor", "DvlVelocityFactor",
-    "PreintegrationParams", "PreintegratedImuMeasurements", "NavState", "ISAM2",
+    "PreintegrationParams", "PreintegratedImuMeasurements", "NavState", "ISAM2", "ConstantTwistScenario",
+    "PinholeCameraCal3_S2",
     "NonlinearFactorGraph", "Values", "LevenbergMarquardtParams", "LevenbergMarquardtOptimizer",
     "StereoFactorBlock", "symbol_shorthand", "symbol",
 ]
@@ -520,6 +521,20 @@ class CustomFactor(_Factor):
 class NavState:
     def __init__(self, pose=None, velocity=None):
         self._pose, self._v = pose or Pose3(), np.zeros(3) if velocity is None else np.asarray(velocity, float)
+
+
+class ConstantTwistScenario:
+    """Imported by batch.py:19-25 and never used; only the name has to exist for the import line."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("ConstantTwistScenario is imported but unused by batch.py; not part of the hot path")
+
+
+class PinholeCameraCal3_S2:
+    """Imported by batch.py:19-25 and never used; only the name has to exist for the import line."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("PinholeCameraCal3_S2 is imported but unused by batch.py; not part of the hot path")
 
 
 class ISAM2:
