@@ -24,6 +24,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import numpy as np
 
 from . import symbol_shorthand  # noqa: F401
+from . import utils  # noqa: F401
 from .symbol_shorthand import symbol, symbolChr, symbolIndex  # noqa: F401
 
 __all__ = [
