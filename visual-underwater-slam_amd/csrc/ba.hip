@@ -622,16 +622,15 @@ __device__ __forceinline__ void panel_update(double (&blk)[6], const double (&xr
 #define VUS_PT(n)
 #define VUS_PP()
 #endif
-// COHERENT: the inputs were written by this workgroup a moment ago (fused launch): read them past the L1.
-template <bool COHERENT>
-__device__ __forceinline__ double panel_ld(const double* p) {
-  return COHERENT ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
-}
-
-template <bool COHERENT>
+// FROM_LDS: the 48x48 block (row stride LDD) and the right-hand-side rows (row stride NB) are handed over in
+// LDS by the workgroup that has just produced them (fused launch) instead of being re-read from memory;
+// only the first lds_poses poses of the panel were touched by that update (bands narrower than a panel),
+// the rest still comes from memory.
+template <bool FROM_LDS>
 __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, int k0, double* yv, size_t ystride,
                                              int n_rhs, int* __restrict__ status, double (*s_x)[64 * 6],
-                                             int& s_bad) {
+                                             int& s_bad, const double* lds_tile = nullptr,
+                                             const double* lds_rhs = nullptr, int lds_poses = 0) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
@@ -647,13 +646,15 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
 #pragma unroll
     for (int c = 0; c < 6; ++c) row[j][c] = 0.0;
     if (R < nb && kb <= ii && ii - kb <= band) {
-      const double* src = blk_ptr(Sb, band, k0 + ii, k0 + kb) + 6 * rr;
+      const double* src = (FROM_LDS && ii < lds_poses) ? lds_tile + R * LDD + 6 * kb
+                                                       : blk_ptr(Sb, band, k0 + ii, k0 + kb) + 6 * rr;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) row[j][c] = panel_ld<COHERENT>(src + c);
+      for (int c = 0; c < 6; ++c) row[j][c] = src[c];
     }
     if (is_rhs && kb < pb) {
+      const double* src = (FROM_LDS && kb < lds_poses) ? lds_rhs + (R - nb) * NB + 6 * kb : yrow + 6 * kb;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) row[j][c] = panel_ld<COHERENT>(yrow + 6 * kb + c);
+      for (int c = 0; c < 6; ++c) row[j][c] = src[c];
     }
   }
   VUS_PT(0);
@@ -723,7 +724,7 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
   VUS_PT(2);
   __syncthreads();
   VUS_PT(3);
-  if (COHERENT && threadIdx.x == 0 && k0 == 808) VUS_PP();
+  if (FROM_LDS && threadIdx.x == 0 && k0 == 808) VUS_PP();
   if (threadIdx.x == 0 && s_bad != 0x7FFFFFFF && status[0] == 0) status[0] = s_bad;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -758,6 +759,7 @@ __global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb
 // Update tiles: one workgroup per UT x UT tile of the lower triangle, (UT/16)^2 MFMA tiles of 16x16
 // shared by 4 waves, K = 48 = 12 steps of v_mfma_f64_16x16x4_f64.  The right-hand sides ride along:
 // y_i -= X_i y_panel (done by the diagonal tiles).
+constexpr int BS_RHS_MAX = 8;      // right-hand sides a solve can carry (= BS_MAX_RHS)
 constexpr int UT = 48;            // scalar rows per tile
 constexpr int UMT = UT / 16;      // MFMA tiles per side
 constexpr int UQ = (UMT * UMT + 3) / 4;   // MFMA tiles per wave
@@ -1047,6 +1049,11 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (ok[q][r]) Sb[off[q][r]] = -acc[q][r];
+    if (blockIdx.x == 0) {   // tile (0,0) also leaves its result in LDS (sL is free) for the panel factorisation below
+      const int Cc = 16 * b + arow;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sL[(16 * a + kq + 4 * r) * LDD + Cc] = -acc[q][r];
+    }
   }
   VUS_TMARK(6);
   if (ti == tj && tid < UT) {
@@ -1057,18 +1064,19 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
         double acc = 0.0;
 #pragma unroll 8
         for (int c = 0; c < NB; ++c) acc += Xi[tid * ULD + c] * Xj[NB * q + c];
-        yq[6 * (size_t)i + (tid % 6)] -= acc;
+        const double ynew = yq[6 * (size_t)i + (tid % 6)] - acc;
+        yq[6 * (size_t)i + (tid % 6)] = ynew;
+        if (blockIdx.x == 0) Xj[NB * BS_RHS_MAX + NB * q + tid] = ynew;   // the next panel's right-hand-side rows
       }
   }
   VUS_TMARK(7);
   if (blockIdx.x == 0) {
     // Tile (0,0) is the next panel's diagonal block, complete once this workgroup has stored it: factor it
     // here instead of in a launch of its own (the other ~400 workgroups of this launch take as long anyway).
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    __builtin_amdgcn_s_waitcnt(0);     // this wave's stores have reached the L2
-    __syncthreads();                   // ... and so have the other waves'; the X tiles in LDS are dead
+    __syncthreads();                   // the LDS copies are complete; the X tiles in LDS are dead
     panel_factor<true>(Sb, n_poses, band, i_first, yv, ystride, n_rhs, status,
-                       reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad);
+                       reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad, sL, Xj + NB * BS_RHS_MAX,
+                       min(PB, i_last - i_first + 1));
 #ifdef VUS_TIMING
     if (threadIdx.x == 0 && k0 == 800) {
       const unsigned long long t8 = __builtin_amdgcn_s_memtime();
