@@ -100,6 +100,9 @@ __device__ __forceinline__ bool nms_keep(const uint32_t (&c)[3][3]) {
   return s > m;
 }
 
+#ifndef VUS_FAST_DIAG
+#define VUS_FAST_DIAG 1   // pre-test also on the two diagonal opposite pairs: survivors 33 % -> 25 %, 6.32 -> 6.23 ms
+#endif
 template <bool WRITE_SCORE, bool DETECT, bool BLUR>
 __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
     const uint8_t* __restrict__ img, int H, int W, int pitch, int thr, int border,
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
   if (WRITE_SCORE || DETECT) {
     // Pass 1 -- cheap necessary test on every pixel of the tile plus a ring (the 3x3 non-max
     // suppression needs 1 pixel), one strip of 4 per item.  A 9-long arc of the 16-circle always
-    // contains one of N/S and one of E/W, so a corner needs  min(max(N,S), max(E,W)) > p + thr  or
-    // max(min(N,S), min(E,W)) < p - thr.  Survivors are compacted into an LDS work list (wave prefix
+    // contains one pixel of every opposite pair, so a corner needs  min over the tested pairs of max(pair) > p + thr
+    // or  max over the pairs of min(pair) < p - thr  (pairs tested: N/S, E/W and the two diagonals).  Survivors are compacted into an LDS work list (wave prefix
     // sum with DPP, one LDS atomic per wave) so that pass 2 runs the full score on dense lanes.
     for (int idx0 = 0; idx0 < SC_ROWS * SC_DW; idx0 += NTHREADS) {   // uniform trip count (wave scans inside)
       const int idx = idx0 + tid;
@@ -170,11 +173,23 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
           const uint32_t nn = s_img[sr * IMG_DW + ss + 1], so = s_img[(sr + 6) * IMG_DW + ss + 1];
           const uint32_t wv = __builtin_amdgcn_alignbyte(b, a, 1);   // bytes x-3 of the 4 pixels
           const uint32_t ev = __builtin_amdgcn_alignbyte(c, b, 3);   // bytes x+3
+#if VUS_FAST_DIAG
+          // the diagonal opposite pairs of the circle, (x+2,y-2)/(x-2,y+2) and (x+2,y+2)/(x-2,y-2)
+          const uint32_t* up = &s_img[(sr + 1) * IMG_DW + ss];
+          const uint32_t* dn = &s_img[(sr + 5) * IMG_DW + ss];
+          const uint32_t nev = __builtin_amdgcn_alignbyte(up[2], up[1], 2), nwv = __builtin_amdgcn_alignbyte(up[1], up[0], 2);
+          const uint32_t sev = __builtin_amdgcn_alignbyte(dn[2], dn[1], 2), swv = __builtin_amdgcn_alignbyte(dn[1], dn[0], 2);
+#endif
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int p = byte_of(b, e);
             const int n_ = byte_of(nn, e), s_ = byte_of(so, e), w_ = byte_of(wv, e), e_ = byte_of(ev, e);
-            const int hi = min(max(n_, s_), max(e_, w_)), lo = max(min(n_, s_), min(e_, w_));
+            int hi = min(max(n_, s_), max(e_, w_)), lo = max(min(n_, s_), min(e_, w_));
+#if VUS_FAST_DIAG
+            const int ne = byte_of(nev, e), sw = byte_of(swv, e), se = byte_of(sev, e), nw = byte_of(nwv, e);
+            hi = min3i(hi, max(ne, sw), max(se, nw));
+            lo = max3i(lo, min(ne, sw), min(se, nw));
+#endif
             mask |= (hi > p + thr || lo < p - thr) ? (1 << e) : 0;
           }
           if (gx < 3 || gx + 3 >= W - 3) {   // strips straddling the 3-pixel frame (edge tiles only)
