@@ -347,6 +347,8 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
     int max_kp, int sort_n, uint32_t* __restrict__ kp_keys, int* __restrict__ kp_count) {
   extern __shared__ uint32_t s_sort[];
   __shared__ int s_hist[256];
+  __shared__ int s_scan[256];
+  __shared__ int s_wtot[4];
   __shared__ uint32_t s_prefix;
   __shared__ int s_k, s_out;
   const int tid = threadIdx.x;
@@ -369,15 +371,31 @@ __global__ __launch_bounds__(SEL_THREADS) void select_topk_kernel(
         if ((k & mask) == prefix) atomicAdd(&s_hist[(k >> shift) & 255], 1);
       }
       __syncthreads();
-      if (tid == 0) {
-        int k = s_k, cum = 0, b = 0;
-        for (; b < 256; ++b) {
-          int h = s_hist[b];
-          if (cum + h >= k) break;
-          cum += h;
+      // the bucket that holds the k-th smallest key: parallel inclusive scan of the 256 counts (a one-thread
+      // walk over the bins cost 10 us per pass)
+      const int kk = s_k;
+      __syncthreads();   // everybody has read s_k and s_prefix before they are rewritten
+      if (tid < 256) {
+        const int h = s_hist[tid];
+        int incl = h;   // inclusive scan inside the wave (DPP row shifts / broadcasts)
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xf, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xf, 0xe, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xf, 0xc, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xa, 0xf, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xc, 0xf, true);
+        if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+        s_scan[tid] = incl;
+      }
+      __syncthreads();
+      if (tid < 256) {
+        int base = 0;
+        for (int w = 0; w < (tid >> 6); ++w) base += s_wtot[w];
+        const int incl = s_scan[tid] + base, excl = incl - s_hist[tid];
+        if (excl < kk && kk <= incl) {   // exactly one bucket
+          s_prefix = prefix | ((uint32_t)tid << shift);
+          s_k = kk - excl;
         }
-        s_prefix = prefix | ((uint32_t)b << shift);
-        s_k = k - cum;
       }
       mask |= 0xFFu << shift;
       __syncthreads();
