@@ -131,6 +131,22 @@ def test_band_solve_random_spd_bands(gpu, oracle):
         assert relerr(d_x.cpu().numpy().reshape(-1), x) < 1e-10, (nP, B)
 
 
+def test_cooperative_band_solve_is_repeatable(gpu, oracle):
+    """The multi-workgroup back-substitution (flags + f64 atomics): 25 repeated solves, status 0 every time and the
+    same answer to 1e-12 (tools/soak_band_solve.py runs 400 at the configs[2] size)."""
+    s, prob, sv, P = setup(oracle, 150, 4000, 300)
+    sv.linearize(torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda())
+    ref = None
+    for _ in range(25):
+        sv.schur(1e-5)
+        sv.band_solve()
+        assert int(sv.status.item()) == 0
+        dp = sv.dp.clone()
+        if ref is None:
+            ref = dp
+        assert float((dp - ref).abs().max() / ref.abs().max()) < 1e-12
+
+
 @pytest.mark.parametrize("size", [(50, 500, 100), (150, 4000, 300)])
 def test_lm_matches_oracle_trajectory_and_result(gpu, oracle, size):
     """Same accepted/rejected sequence, same error history, same optimum as the CPU oracle."""
