@@ -114,6 +114,12 @@ int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, const int* 
                       int max_dy, int min_disp, int max_disp, int max_dist,
                       int32_t* idx_out, int32_t* dist_out, void* stream);
 
+/* Optional mutual-nearest-neighbour filter ("cross-check"): a match i -> j of the forward pairing survives
+ * only if the backward pairing (query and train sets swapped) matches j -> i.
+ * idx_fwd, idx_bwd, idx_out: int32 [n_pairs, max_kp]; idx_out may alias idx_fwd. */
+int vus_cross_check(const int32_t* idx_fwd, const int32_t* idx_bwd, int n_pairs, int max_kp, int32_t* idx_out,
+                    void* stream);
+
 /* CameraMeasurement emitter (what batch.py:149-154 reads from the nodelet's message): persistent
  * feature ids propagated along the left(t)->left(t+1) matches, and the features' normalised image
  * coordinates.  Frame f's left image is image 2f, its right image 2f+1 (as in vus_hamming_match).

@@ -140,6 +140,14 @@ def hamming_match(desc, kp_keys, kp_count, W, q_index, t_index, max_dy=-1, min_d
     return idx, dist
 
 
+def cross_check(idx_fwd, idx_bwd):
+    idx_fwd = np.ascontiguousarray(idx_fwd, np.int32)
+    idx_bwd = np.ascontiguousarray(idx_bwd, np.int32)
+    out = np.empty_like(idx_fwd)
+    _check(lib().vus_cross_check_cpu(_p(idx_fwd), _p(idx_bwd), idx_fwd.shape[0], idx_fwd.shape[1], _p(out)), "cross_check")
+    return out
+
+
 def track_ids(stereo_idx, track_idx, kp_keys, kp_count, H, W):
     stereo_idx = np.ascontiguousarray(stereo_idx, np.int32)
     F, K = stereo_idx.shape

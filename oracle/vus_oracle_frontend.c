@@ -308,6 +308,17 @@ int vus_hamming_match_cpu(const uint64_t* desc, const uint32_t* kp_keys, const i
 }
 
 /* CameraMeasurement emitter: ids along the temporal matches, frame by frame (see include/vus.h). */
+/* Mutual-nearest-neighbour filter (include/vus.h: vus_cross_check). */
+int vus_cross_check_cpu(const int32_t* idx_fwd, const int32_t* idx_bwd, int n_pairs, int max_kp, int32_t* idx_out) {
+  if (!idx_fwd || !idx_bwd || !idx_out || n_pairs < 0 || max_kp < 1) return VUS_E_INVALID;
+  for (int p = 0; p < n_pairs; ++p)
+    for (int i = 0; i < max_kp; ++i) {
+      const int32_t j = idx_fwd[(size_t)p * max_kp + i];
+      idx_out[(size_t)p * max_kp + i] = (j >= 0 && j < max_kp && idx_bwd[(size_t)p * max_kp + j] == i) ? j : -1;
+    }
+  return VUS_OK;
+}
+
 int vus_track_ids_cpu(const int32_t* stereo_idx, const int32_t* track_idx, const uint32_t* kp_keys,
                       const int* kp_count, int n_frames, int max_kp, int H, int W, int64_t* ids_out,
                       double* feat_out, int64_t* n_ids_out) {

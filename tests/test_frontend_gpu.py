@@ -434,3 +434,31 @@ def test_pyramid_pipeline_matches_oracle_chain(gpu, oracle, shape, levels, kmax)
     assert (sidx[0, :kc[0]] >= 0).sum() > 50
     msgs = fe.camera_measurements(res)
     assert len(msgs) == F and len(msgs[0].features) > 50
+
+
+def test_cross_check_keeps_only_mutual_matches(gpu, oracle):
+    """ImageProcessorParams(cross_check=True): forward matches filtered by the backward pairing == the oracle chain."""
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    F, H, W, K = 3, 240, 320, 400
+    img = synth.stereo_frames(21, F, H=H, W=W)
+    p = ImageProcessorParams(max_features=K, cross_check=True)
+    fe = StereoOrbFrontend(H, W, max_frames=F, params=p)
+    res = fe.process(torch.from_numpy(img).cuda())
+    torch.cuda.synchronize()
+    kp, kc, blur, desc, ang = _pipeline_oracle(oracle, img.reshape(2 * F, H, W), K)
+    f = np.arange(F, dtype=np.int32)
+    fwd, _ = oracle.hamming_match(desc, kp, kc, W, 2 * f, 2 * f + 1, p.stereo_threshold, p.min_disparity, p.max_disparity,
+                                  p.stereo_max_distance, H=H)
+    bwd, _ = oracle.hamming_match(desc, kp, kc, W, 2 * f + 1, 2 * f, p.stereo_threshold, -p.max_disparity, -p.min_disparity,
+                                  p.stereo_max_distance, H=H)
+    want = oracle.cross_check(fwd, bwd)
+    assert np.array_equal(res.stereo_idx.cpu().numpy(), want)
+    tf, _ = oracle.hamming_match(desc, kp, kc, W, 2 * f[:-1], 2 * f[:-1] + 2, -1, 0, 0, p.track_max_distance, H=H)
+    tb, _ = oracle.hamming_match(desc, kp, kc, W, 2 * f[:-1] + 2, 2 * f[:-1], -1, 0, 0, p.track_max_distance, H=H)
+    assert np.array_equal(res.track_idx.cpu().numpy(), oracle.cross_check(tf, tb))
+    kept, before = int((want >= 0).sum()), int((fwd >= 0).sum())
+    assert 0 < kept <= before
+    # mutual by construction
+    for r in range(F):
+        for i in np.nonzero(want[r] >= 0)[0][:50]:
+            assert bwd[r, want[r, i]] == i

@@ -1224,6 +1224,16 @@ __global__ __launch_bounds__(256) void pyramid_append_kernel(const uint32_t* __r
   if (threadIdx.x == 0) kp_count[n] = base + cnt;
 }
 
+__global__ void cross_check_kernel(const int32_t* __restrict__ idx_fwd, const int32_t* __restrict__ idx_bwd, int max_kp,
+                                   long long total, int32_t* __restrict__ idx_out) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= total) return;
+  const long long row = t / max_kp;
+  const int i = (int)(t - row * max_kp);
+  const int32_t j = idx_fwd[t];
+  idx_out[t] = (j >= 0 && j < max_kp && idx_bwd[row * max_kp + j] == i) ? j : -1;
+}
+
 }  // namespace
 
 extern "C" int vus_fast_score(const uint8_t* img, int n_img, int H, int W, int pitch, int thr,
@@ -1411,5 +1421,17 @@ extern "C" int vus_pyramid_append(const uint32_t* lvl_keys, const int* lvl_count
                                                                    Hl, Wl, level, H0, W0, max_kp, kp_keys, kp_count,
                                                                    desc, angle, kp_level, kp_xy_q4);
   VUS_CHECK_LAUNCH("pyramid_append");
+  return VUS_OK;
+}
+
+extern "C" int vus_cross_check(const int32_t* idx_fwd, const int32_t* idx_bwd, int n_pairs, int max_kp,
+                               int32_t* idx_out, void* stream) {
+  VUS_REQUIRE(idx_fwd && idx_bwd && idx_out, "null buffer");
+  VUS_REQUIRE(n_pairs >= 0 && max_kp >= 1, "n_pairs=%d max_kp=%d", n_pairs, max_kp);
+  const long long total = (long long)n_pairs * max_kp;
+  if (total == 0) return VUS_OK;
+  cross_check_kernel<<<(unsigned)((total + 255) / 256), 256, 0, vus::as_stream(stream)>>>(idx_fwd, idx_bwd, max_kp, total,
+                                                                                       idx_out);
+  VUS_CHECK_LAUNCH("cross_check");
   return VUS_OK;
 }

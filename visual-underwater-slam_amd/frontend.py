@@ -30,6 +30,7 @@ class ImageProcessorParams:
     stereo_max_distance: int = 64  # Hamming acceptance thresholds
     track_max_distance: int = 64
     cand_cap: int = 32768          # candidate slots per image before top-K selection
+    cross_check: bool = False      # keep a match only if it is mutual (query <-> train swapped gives it back)
     n_levels: int = 1              # ORB scale pyramid: 1 = single level; 8 with scale_factor 1.2 = Rublee et al.
     scale_factor: float = 1.2
 
@@ -127,6 +128,9 @@ class StereoOrbFrontend:
         self.track_q, self.track_t = (2 * f).contiguous(), (2 * f + 2).contiguous()
         self.kp_level = self.kp_xy_q4 = None
         self.levels = None
+        if self.p.cross_check:   # backward pairings (same row layout as match_idx)
+            self.rev_idx = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
+            self.rev_dist = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
         if self.p.n_levels > 1:
             # per-level workspaces: image (levels >= 1), smoothed image, keys, descriptors
             sizes, quotas = pyramid_layout(H, W, K, self.p.n_levels, self.p.scale_factor)
@@ -173,6 +177,18 @@ class StereoOrbFrontend:
             _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, H, W,
                       ptr(self.track_q), ptr(self.track_t), F - 1, -1, 0, 0, p.track_max_distance,
                       ptr(self.match_idx[self.max_frames:]), ptr(self.match_dist[self.max_frames:]), st)
+        if p.cross_check:
+            # backward pairings: right -> left under the mirrored disparity gate, left(t+1) -> left(t)
+            _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, H, W,
+                      ptr(self.stereo_t), ptr(self.stereo_q), F, p.stereo_threshold, -p.max_disparity,
+                      -p.min_disparity, p.stereo_max_distance, ptr(self.rev_idx), ptr(self.rev_dist), st)
+            _lib.call("vus_cross_check", ptr(self.match_idx), ptr(self.rev_idx), F, K, ptr(self.match_idx), st)
+            if F > 1:
+                _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, H, W,
+                          ptr(self.track_t), ptr(self.track_q), F - 1, -1, 0, 0, p.track_max_distance,
+                          ptr(self.rev_idx[self.max_frames:]), ptr(self.rev_dist[self.max_frames:]), st)
+                _lib.call("vus_cross_check", ptr(self.match_idx[self.max_frames:]), ptr(self.rev_idx[self.max_frames:]),
+                          F - 1, K, ptr(self.match_idx[self.max_frames:]), st)
         if check:
             self.check_overflow(n_img)
         return FrontendResult(self, F)
