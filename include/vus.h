@@ -69,6 +69,15 @@ int vus_fast_detect(const uint8_t* img, int n_img, int H, int W, int pitch, int 
 int vus_select_topk(const uint32_t* cand_keys, const int* cand_count, int n_img, int cand_cap,
                     int max_kp, uint32_t* kp_keys, int* kp_count, void* stream);
 
+/* Grid-bucketed selection, the nodelet's grid_row / grid_col / grid_max_feature_num parameters
+ * (launch/stereo.launch:36-39): the image is cut into grid_row x grid_col cells (cell of a pixel:
+ * cy = y * grid_row / H, cx = x * grid_col / W, integer division) and every cell keeps its per_cell smallest
+ * keys.  Output: cells in row-major order, each cell's keys ascending, packed from slot 0;
+ * kp_count = number kept (<= min(max_kp, grid_row * grid_col * per_cell)); unused tail = VUS_KEY_INVALID. */
+int vus_select_grid(const uint32_t* cand_keys, const int* cand_count, int n_img, int cand_cap, int H, int W,
+                    int grid_row, int grid_col, int per_cell, int max_kp, uint32_t* kp_keys, int* kp_count,
+                    void* stream);
+
 /* Orientation (intensity centroid over the radius-15 disc of `img`, quantised to 30 bins with
  * integer arithmetic) and 256-bit rotated-BRIEF descriptor sampled from `blur`.
  * desc_out: uint64 [n_img, max_kp, 4] (bit b of word w = test 64*w + b, set when I(p0) < I(p1));

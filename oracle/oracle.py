@@ -80,6 +80,17 @@ def select_topk(cand_keys, cand_count, max_kp):
     return kp, cnt
 
 
+def select_grid(cand_keys, cand_count, H, W, grid_row, grid_col, per_cell, max_kp):
+    cand_keys = np.ascontiguousarray(cand_keys, np.uint32)
+    cand_count = np.ascontiguousarray(cand_count, np.int32)
+    n, cap = cand_keys.shape
+    kp = np.empty((n, max_kp), np.uint32)
+    cnt = np.empty(n, np.int32)
+    _check(lib().vus_select_grid_cpu(_p(cand_keys), _p(cand_count), n, cap, int(H), int(W), int(grid_row), int(grid_col),
+                                     int(per_cell), int(max_kp), _p(kp), _p(cnt)), "select_grid")
+    return kp, cnt
+
+
 def orient_rbrief(img, blur, kp_keys, kp_count):
     img, n, H, W = _img_args(img)
     blur = np.ascontiguousarray(blur, np.uint8)

@@ -165,6 +165,42 @@ int vus_select_topk_cpu(const uint32_t* cand_keys, const int* cand_count, int n_
   return VUS_OK;
 }
 
+/* Grid-bucketed selection (include/vus.h: vus_select_grid). */
+int vus_select_grid_cpu(const uint32_t* cand_keys, const int* cand_count, int n_img, int cand_cap, int H, int W,
+                        int grid_row, int grid_col, int per_cell, int max_kp, uint32_t* kp_keys, int* kp_count) {
+  if (!cand_keys || !cand_count || !kp_keys || !kp_count || cand_cap < 1 || H < 1 || W < 1 || grid_row < 1 ||
+      grid_col < 1 || per_cell < 1 || max_kp < 1)
+    return VUS_E_INVALID;
+  for (int n = 0; n < n_img; ++n) {
+    const uint32_t* keys = cand_keys + (size_t)n * cand_cap;
+    const int cnt = cand_count[n] < cand_cap ? cand_count[n] : cand_cap;
+    uint32_t* o = kp_keys + (size_t)n * max_kp;
+    int out = 0;
+    for (int cell = 0; cell < grid_row * grid_col; ++cell) {
+      const int cy = cell / grid_col, cx = cell - cy * grid_col;
+      uint32_t last = 0;
+      int have_last = 0;
+      for (int j = 0; j < per_cell && out < max_kp; ++j) {
+        uint32_t best = VUS_KEY_INVALID;
+        for (int i = 0; i < cnt; ++i) {
+          const uint32_t k = keys[i];
+          const int pos = (int)(k & VUS_KEY_POS_MASK), y = pos / W, x = pos - y * W;
+          if (y * grid_row / H != cy || x * grid_col / W != cx) continue;
+          if (have_last && k <= last) continue;
+          if (k < best) best = k;
+        }
+        if (best == VUS_KEY_INVALID) break;
+        o[out++] = best;
+        last = best;
+        have_last = 1;
+      }
+    }
+    kp_count[n] = out;
+    for (int i = out; i < max_kp; ++i) o[i] = VUS_KEY_INVALID;
+  }
+  return VUS_OK;
+}
+
 int vus_orient_rbrief_cpu(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
                           const uint32_t* kp_keys, const int* kp_count, int max_kp,
                           uint64_t* desc_out, uint8_t* angle_out) {

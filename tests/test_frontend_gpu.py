@@ -462,3 +462,36 @@ def test_cross_check_keeps_only_mutual_matches(gpu, oracle):
     for r in range(F):
         for i in np.nonzero(want[r] >= 0)[0][:50]:
             assert bwd[r, want[r, i]] == i
+
+
+@pytest.mark.parametrize("grid", [(3, 4, 4, 64), (5, 7, 3, 50), (1, 1, 6, 6)])
+def test_select_grid_bit_exact_and_in_the_pipeline(gpu, oracle, grid):
+    """Grid-bucketed selection (the nodelet's grid_row / grid_col / grid_max_feature_num) == the oracle, both as
+    a kernel and through StereoOrbFrontend."""
+    import visual_underwater_slam_amd._lib as L
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    gr, gc, per, K = grid
+    F, H, W = 2, 240, 320
+    img = synth.stereo_frames(33, F, H=H, W=W)
+    flat = img.reshape(2 * F, H, W)
+    ck, cc, blur = oracle.fast_detect(flat, 10, 31, 32768)
+    want, wc = oracle.select_grid(ck, cc, H, W, gr, gc, per, K)
+    keys = torch.empty((2 * F, K), dtype=torch.int32, device="cuda")
+    cnt = torch.empty(2 * F, dtype=torch.int32, device="cuda")
+    L.call("vus_select_grid", _dev(ck.view(np.int32)).data_ptr(), _dev(cc).data_ptr(), 2 * F, ck.shape[1], H, W, gr, gc,
+           per, K, keys.data_ptr(), cnt.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(cnt.cpu().numpy(), wc) and np.array_equal(_u32(keys), want)
+    assert wc.max() <= min(K, gr * gc * per) and wc.min() > 0
+    # every kept keypoint lies in the cell its slot order says, at most `per` per cell
+    pos = want[0, :wc[0]] & 0xFFFFFF
+    cells = (pos // W) * gr // H * gc + (pos % W) * gc // W
+    assert (np.diff(cells.astype(np.int64)) >= 0).all() and np.bincount(cells, minlength=gr * gc).max() <= per
+    fe = StereoOrbFrontend(H, W, max_frames=F, params=ImageProcessorParams(max_features=K, grid_row=gr, grid_col=gc,
+                                                                           grid_max_feature_num=per))
+    res = fe.process(torch.from_numpy(img).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(_u32(res.kp_keys), want) and np.array_equal(res.kp_count.cpu().numpy(), wc)
+    desc, ang = oracle.orient_rbrief(flat, blur, want, wc)
+    for n in range(2 * F):
+        assert np.array_equal(res.desc.cpu().numpy().view(np.uint64)[n, :wc[n]], desc[n, :wc[n]])

@@ -17,6 +17,7 @@ SIGNATURES = {
     "vus_orient_rbrief": [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P],
     "vus_hamming_match": [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "vus_triangulate": [_P, c_int, _P, _P, _P, _P],
+    "vus_select_grid": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "vus_cross_check": [_P, _P, c_int, c_int, _P, _P],
     "vus_resize_bilinear": [_P, c_int, c_int, c_int, c_int, _P, c_int, c_int, c_int, _P],
     "vus_pyramid_append": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,

@@ -1234,6 +1234,54 @@ __global__ void cross_check_kernel(const int32_t* __restrict__ idx_fwd, const in
   idx_out[t] = (j >= 0 && j < max_kp && idx_bwd[row * max_kp + j] == i) ? j : -1;
 }
 
+// Grid-bucketed selection: one workgroup per image walks the cells in row-major order; per cell, per_cell
+// rounds of "smallest key of the cell above the previous pick" (block-wide min), appended in order.
+__global__ __launch_bounds__(SEL_THREADS) void select_grid_kernel(const uint32_t* __restrict__ cand_keys,
+                                                                  const int* __restrict__ cand_count, int cand_cap,
+                                                                  int H, int W, int grid_row, int grid_col, int per_cell,
+                                                                  int max_kp, uint32_t* __restrict__ kp_keys,
+                                                                  int* __restrict__ kp_count) {
+  __shared__ uint32_t s_min[SEL_THREADS / 64];
+  __shared__ uint32_t s_pick;
+  const int tid = threadIdx.x, n = blockIdx.x;
+  const uint32_t* keys = cand_keys + (size_t)n * cand_cap;
+  const int cnt = min(cand_count[n], cand_cap);
+  uint32_t* o = kp_keys + (size_t)n * max_kp;
+  int out = 0;
+  for (int cell = 0; cell < grid_row * grid_col && out < max_kp; ++cell) {
+    const int cy = cell / grid_col, cx = cell - cy * grid_col;
+    uint32_t last = 0;
+    bool have_last = false;
+    for (int j = 0; j < per_cell && out < max_kp; ++j) {
+      uint32_t best = VUS_KEY_INVALID;
+      for (int i = tid; i < cnt; i += SEL_THREADS) {
+        const uint32_t k = keys[i];
+        const int pos = (int)(k & VUS_KEY_POS_MASK), y = pos / W, x = pos - y * W;
+        if (y * grid_row / H == cy && x * grid_col / W == cx && !(have_last && k <= last)) best = min(best, k);
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) best = min(best, (uint32_t)__shfl_xor((int)best, off));
+      if ((tid & 63) == 0) s_min[tid >> 6] = best;
+      __syncthreads();
+      if (tid == 0) {
+        uint32_t b = s_min[0];
+        for (int w = 1; w < SEL_THREADS / 64; ++w) b = min(b, s_min[w]);
+        s_pick = b;
+      }
+      __syncthreads();
+      const uint32_t pick = s_pick;
+      __syncthreads();   // s_pick / s_min are rewritten in the next round
+      if (pick == VUS_KEY_INVALID) break;
+      if (tid == 0) o[out] = pick;
+      ++out;
+      last = pick;
+      have_last = true;
+    }
+  }
+  for (int i = out + tid; i < max_kp; i += SEL_THREADS) o[i] = VUS_KEY_INVALID;
+  if (tid == 0) kp_count[n] = out;
+}
+
 }  // namespace
 
 extern "C" int vus_fast_score(const uint8_t* img, int n_img, int H, int W, int pitch, int thr,
@@ -1433,5 +1481,20 @@ extern "C" int vus_cross_check(const int32_t* idx_fwd, const int32_t* idx_bwd, i
   cross_check_kernel<<<(unsigned)((total + 255) / 256), 256, 0, vus::as_stream(stream)>>>(idx_fwd, idx_bwd, max_kp, total,
                                                                                        idx_out);
   VUS_CHECK_LAUNCH("cross_check");
+  return VUS_OK;
+}
+
+extern "C" int vus_select_grid(const uint32_t* cand_keys, const int* cand_count, int n_img, int cand_cap, int H, int W,
+                               int grid_row, int grid_col, int per_cell, int max_kp, uint32_t* kp_keys, int* kp_count,
+                               void* stream) {
+  VUS_REQUIRE(cand_keys && cand_count && kp_keys && kp_count, "null buffer");
+  VUS_REQUIRE(n_img >= 0 && cand_cap >= 1 && max_kp >= 1, "n_img=%d cand_cap=%d max_kp=%d", n_img, cand_cap, max_kp);
+  VUS_REQUIRE(H >= 1 && W >= 1 && H < 32768 && W < 32768, "H=%d W=%d", H, W);
+  VUS_REQUIRE(grid_row >= 1 && grid_col >= 1 && grid_row <= 256 && grid_col <= 256 && per_cell >= 1,
+              "grid %dx%d per_cell=%d", grid_row, grid_col, per_cell);
+  if (n_img == 0) return VUS_OK;
+  select_grid_kernel<<<n_img, SEL_THREADS, 0, vus::as_stream(stream)>>>(cand_keys, cand_count, cand_cap, H, W, grid_row,
+                                                                        grid_col, per_cell, max_kp, kp_keys, kp_count);
+  VUS_CHECK_LAUNCH("select_grid");
   return VUS_OK;
 }

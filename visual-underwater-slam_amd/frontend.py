@@ -30,6 +30,9 @@ class ImageProcessorParams:
     stereo_max_distance: int = 64  # Hamming acceptance thresholds
     track_max_distance: int = 64
     cand_cap: int = 32768          # candidate slots per image before top-K selection
+    grid_row: int = 0              # stereo.launch:36-39 -- with grid_max_feature_num > 0 every cell of the
+    grid_col: int = 0              # grid_row x grid_col grid keeps its grid_max_feature_num best corners
+    grid_max_feature_num: int = 0  # (the nodelet's values: 3 x 4 cells, 4 per cell); 0 = global top max_features
     cross_check: bool = False      # keep a match only if it is mutual (query <-> train swapped gives it back)
     n_levels: int = 1              # ORB scale pyramid: 1 = single level; 8 with scale_factor 1.2 = Rublee et al.
     scale_factor: float = 1.2
@@ -109,6 +112,9 @@ class StereoOrbFrontend:
         _lib.require_gpu()
         _lib.load()
         self.p = params or ImageProcessorParams()
+        if self.p.grid_max_feature_num > 0:
+            assert self.p.grid_row >= 1 and self.p.grid_col >= 1 and self.p.n_levels == 1, \
+                "grid bucketing needs grid_row, grid_col >= 1 and a single pyramid level"
         self.H, self.W, self.max_frames = int(H), int(W), int(max_frames)
         self.device = torch.device(device)
         n_img, K, cap = 2 * self.max_frames, self.p.max_features, self.p.cand_cap
@@ -164,8 +170,12 @@ class StereoOrbFrontend:
             self.cand_count[:n_img].zero_()
             _lib.call("vus_fast_detect", ptr(images), n_img, H, W, W, p.fast_threshold, p.border,
                       ptr(self.blur), ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
-            _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, K,
-                      ptr(self.kp_keys), ptr(self.kp_count), st)
+            if p.grid_max_feature_num > 0:
+                _lib.call("vus_select_grid", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, H, W,
+                          p.grid_row, p.grid_col, p.grid_max_feature_num, K, ptr(self.kp_keys), ptr(self.kp_count), st)
+            else:
+                _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, K,
+                          ptr(self.kp_keys), ptr(self.kp_count), st)
             _lib.call("vus_orient_rbrief", ptr(images), ptr(self.blur), n_img, H, W, W, ptr(self.kp_keys),
                       ptr(self.kp_count), K, ptr(self.desc), ptr(self.angle), st)
         else:
