@@ -1105,6 +1105,10 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
 constexpr int BS_MAX_RHS = 8;
 constexpr int CB_THREADS = 512;          // 8 solver waves at most; threads < 8 * 48 = (panel row kk, output 6a + c)
 constexpr int CB_SPIN_LIMIT = 1 << 22;
+#ifndef VUS_CB_MAX_WG
+#define VUS_CB_MAX_WG 96
+#endif
+constexpr int CB_MAX_WG = VUS_CB_MAX_WG;    // solver + helpers
 
 // Data that crosses workgroups (x, y, the flags) is only touched with agent-scope atomics, which are
 // performed at the coherence point themselves; ordering is program order + s_waitcnt vmcnt(0) before a
@@ -1147,7 +1151,8 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(const double
                                                                     int band, double* yv, size_t ystride, int n_rhs,
                                                                     int n_groups, int* F, int* __restrict__ status) {
   if (blockIdx.x & 7) return;
-  const int g = blockIdx.x >> 3;
+  const int g = blockIdx.x >> 3;                 // workgroup index: 0 = solver, w >= 1 serves row groups w, w + n_wg - 1, ...
+  const int n_helpers = (int)(gridDim.x >> 3) - 1;
   __shared__ double s_x[BS_MAX_RHS][NB];
   __shared__ double s_part[BS_MAX_RHS][PB][NB];
   __shared__ double s_own[BS_MAX_RHS][NB];
@@ -1160,9 +1165,9 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(const double
   // this thread's block row for panel p: row c of the transposed block (8p + kk, 8p - 8g - 8 + a)
   d2a_t l[3];
   bool have;
-#define CB_LOAD_ROWS(P)                                                                                \
+#define CB_LOAD_ROWS_G(P, G)                                                                           \
   {                                                                                                    \
-    const int k0_ = PB * (P), i_ = k0_ - PB * g - PB + a;                                              \
+    const int k0_ = PB * (P), i_ = k0_ - PB * (G) - PB + a;                                            \
     have = kk < PB && i_ >= 0 && k0_ + kk < n_poses && k0_ + kk - i_ <= band;                                     \
     const d2a_t* src_ = reinterpret_cast<const d2a_t*>(have ? blk_ptr(Sb, band, k0_ + kk, i_) + 6 * c : Sb); \
     l[0] = src_[0]; l[1] = src_[1]; l[2] = src_[2];                                                    \
@@ -1173,6 +1178,7 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(const double
     const double d = l[0].x * xq[0] + l[0].y * xq[1] + l[1].x * xq[2] + l[1].y * xq[3] + l[2].x * xq[4] + l[2].y * xq[5]; \
     s_part[q][kk][oc] = have ? d : 0.0;                                                                \
   }
+#define CB_LOAD_ROWS(P) CB_LOAD_ROWS_G(P, g)
   CB_LOAD_ROWS(NP - 1);
   if (g == 0) {
     // ---- solver ----
@@ -1231,7 +1237,11 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(const double
       __syncthreads();
     }
   } else {
-    // ---- row group g: panels NP-1 .. g+1 contribute to panels NP-g-2 .. 0 ----
+    // ---- row group gg: panels NP-1 .. gg+1 contribute to panels NP-gg-2 .. 0 ----
+    // Normally one row group per workgroup (its block rows prefetched one panel ahead).  Bands wider than
+    // 8 * n_helpers poses give a workgroup several groups (gg = g, g + n_helpers, ...): all active workgroups
+    // must be co-resident on one XCD for the flag protocol to make progress, so their number is capped.
+    const bool single = g + n_helpers >= n_groups;
     for (int s = 0; s < NP - g - 1; ++s) {
       const int p = NP - 1 - s, k0 = PB * p;
       const int nb = 6 * min(PB, n_poses - k0);
@@ -1246,23 +1256,27 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(const double
                            : 0.0;
       }
       __syncthreads();
-      CB_PARTIAL_DOTS();
-      __syncthreads();
-      if (tid < NB * n_rhs) {
-        const int q = tid / NB, r = tid - NB * q;
-        double sum = 0.0;
+      for (int gg = g; gg < n_groups && s < NP - gg - 1; gg += n_helpers) {
+        if (!single) CB_LOAD_ROWS_G(p, gg);
+        CB_PARTIAL_DOTS();
+        __syncthreads();
+        if (tid < NB * n_rhs) {
+          const int q = tid / NB, r = tid - NB * q;
+          double sum = 0.0;
 #pragma unroll
-        for (int k2 = 0; k2 < PB; ++k2) sum += s_part[q][k2][r];
-        const int row = 6 * (k0 - PB * g - PB) + r;    // >= 0: this group stops at panel g + 1
-        __hip_atomic_fetch_add(&yv[(size_t)q * ystride + row], -sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int k2 = 0; k2 < PB; ++k2) sum += s_part[q][k2][r];
+          const int row = 6 * (k0 - PB * gg - PB) + r;    // >= 0: this group stops at panel gg + 1
+          __hip_atomic_fetch_add(&yv[(size_t)q * ystride + row], -sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        cb_drain();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(F + 2 + gg, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      cb_drain();
-      __syncthreads();
-      if (tid == 0) __hip_atomic_store(F + 2 + g, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (s + 1 < NP - g - 1) CB_LOAD_ROWS(p - 1);
+      if (single && s + 1 < NP - g - 1) CB_LOAD_ROWS(p - 1);
     }
   }
 #undef CB_LOAD_ROWS
+#undef CB_LOAD_ROWS_G
 #undef CB_PARTIAL_DOTS
   if (tid == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) status[0] = -1;
 }
@@ -1514,8 +1528,9 @@ int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, 
   VUS_REQUIRE(F != nullptr, "no scratch for the solver flags");
   VUS_REQUIRE(band == 0 || 2 + n_groups <= 72 * band, "band=%d: too many row groups for the flag area", band);
   VUS_CHECK_HIP(hipMemsetAsync(F, 0, sizeof(int) * (size_t)(2 + n_groups), st));
-  chol_backsolve_kernel<<<8 * n_groups, CB_THREADS, 0, st>>>(Sband, n_nodes, band, y, ystride, n_rhs, n_groups, F,
-                                                             status);
+  // at most CB_MAX_WG cooperating workgroups (all resident on one XCD: 32 CUs x 4 workgroups of 512 threads)
+  const int n_wg = n_groups < CB_MAX_WG ? n_groups : CB_MAX_WG;
+  chol_backsolve_kernel<<<8 * n_wg, CB_THREADS, 0, st>>>(Sband, n_nodes, band, y, ystride, n_rhs, n_groups, F, status);
   VUS_CHECK_LAUNCH("ba_band_solve");
   return VUS_OK;
 }
