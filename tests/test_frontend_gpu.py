@@ -495,3 +495,14 @@ def test_select_grid_bit_exact_and_in_the_pipeline(gpu, oracle, grid):
     desc, ang = oracle.orient_rbrief(flat, blur, want, wc)
     for n in range(2 * F):
         assert np.array_equal(res.desc.cpu().numpy().view(np.uint64)[n, :wc[n]], desc[n, :wc[n]])
+
+
+def test_differential_fuzz_small(gpu, oracle, monkeypatch):
+    """A dozen random configurations (odd sizes, borders below the patch radius, pyramids, cross-check) through
+    tools/fuzz_frontend.py: every stage bit-exact against the oracle chain."""
+    import os
+    import runpy
+    import sys
+    script = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "fuzz_frontend.py")
+    monkeypatch.setattr(sys, "argv", [script, "12", "7"])
+    runpy.run_path(script, run_name="__main__")
