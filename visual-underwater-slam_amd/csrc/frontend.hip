@@ -38,7 +38,10 @@ namespace {
 #endif
 constexpr int TW = VUS_TW;              // output tile width  (1280 = 10 tiles of 128)
 constexpr int TH = VUS_TH;              // output tile height (720 = 30 tiles of 24)
-constexpr int NTHREADS = 256;
+#ifndef VUS_NT
+#define VUS_NT 256
+#endif
+constexpr int NTHREADS = VUS_NT;
 // LDS images are arrays of dwords = 4 horizontally adjacent pixels ("strips"); every phase reads
 // ds_read_b32/b64 and unpacks bytes in registers (byte-wide LDS reads cost ~3x the LDS cycles).
 constexpr int IMG_ROWS = TH + 8;        // image rows  y0-4 .. y0+TH+3
