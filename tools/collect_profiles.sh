@@ -8,10 +8,10 @@ OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # 1. plain bench line (no profiler attached)
-python3 $ROOT/bench.py > $OUT/bench_${TAG}.json 2> $OUT/bench_${TAG}.err || true
+python3 $ROOT/bench.py --pyramid > $OUT/bench_${TAG}.json 2> $OUT/bench_${TAG}.err || true
 # 2. rocprofv3 kernel trace + stats of the same command
-# (single-level headline only: the extra pyramid measurement launches the same kernels at 8 sizes and would blur the averages)
-rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 $ROOT/bench.py --no-pyramid > $OUT/bench_${TAG}_under_rocprof.json 2>/dev/null || true
+# (the default command: single-level headline; --pyramid would launch the same kernels at 8 sizes and blur the averages)
+rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -- python3 $ROOT/bench.py > $OUT/bench_${TAG}_under_rocprof.json 2>/dev/null || true
 python3 $ROOT/tools/summarize_stats.py /tmp/prof_kt 40 | grep -v "at::native\|rocprim\|rocclr\|compute_cuda" > $OUT/kernel_stats_${TAG}.txt || true
 # 3. PMC passes (front-end kernels, 200 frames; separate passes as the guide prescribes)
 pmc() { name=$1; shift; rm -rf /tmp/pmc_$name; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d /tmp/pmc_$name -- python3 $ROOT/bench.py --frames 200 --steps 2 --warmup 1 --no-cpu-baseline --no-ba --no-pyramid > /dev/null 2>&1 || true; }
