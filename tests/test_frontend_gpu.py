@@ -406,7 +406,7 @@ def test_pyramid_pipeline_matches_oracle_chain(gpu, oracle, shape, levels, kmax)
     fe = StereoOrbFrontend(H, W, max_frames=F, params=p)
     res = fe.process(torch.from_numpy(img).cuda())
     torch.cuda.synchronize()
-    m = _pyramid_oracle(oracle, img.reshape(2 * F, H, W), p, H, W)
+    m = _pyramid_oracle(oracle, img.reshape(2 * F, H, W), fe.p, H, W)
     kc = m["kp_count"]
     assert np.array_equal(res.kp_count.cpu().numpy(), kc) and kc.min() > 100
     assert np.array_equal(_u32(res.kp_keys), m["kp_keys"])

@@ -49,7 +49,7 @@ for case in range(n_cases):
     fe = StereoOrbFrontend(H, W, max_frames=F, params=p)
     res = fe.process(torch.from_numpy(img).cuda())
     torch.cuda.synchronize()
-    kp, kc, desc, ang = oracle_chain(img.reshape(2 * F, H, W), p, H, W)
+    kp, kc, desc, ang = oracle_chain(img.reshape(2 * F, H, W), fe.p, H, W)
     tag = f"case {case}: {W}x{H} F={F} levels={levels} K={p.max_features} thr={p.fast_threshold} border={border} xc={p.cross_check}"
     assert np.array_equal(res.kp_count.cpu().numpy(), kc), tag
     assert np.array_equal(res.kp_keys.cpu().numpy().view(np.uint32), kp), tag

@@ -10,17 +10,24 @@
 // permutations precomputed; per-observation 6x3 products W, Y in P-order so that every block of the
 // reduced camera system reads two compact per-pose segments.
 //
-// Kernel map (all deterministic: no float atomics, fixed-order wave/LDS reductions):
+// Kernel map.  Reductions are fixed-order wave / LDS / DPP sums everywhere except the cooperative
+// back-substitution of the band solve, which adds its partial products into the right-hand side with f64
+// atomics: two solves of the same system agree to ~1e-13 relative, not bitwise (the landmark-sharded
+// solver broadcasts rank 0's dp for that reason, dist.py).
 //   lin_points   wave / point      r, H1, H2 -> W (scatter to P-order), V, gl, error partial
 //   lin_poses    workgroup / pose  r, H1 (recomputed, never stored) -> Hpp, gp
 //   priors       one lane          PriorFactorPose3 information / gradient / error
 //   vinv, ymul   thread / point, thread / obs   (V + lambda I)^-1,  Y = W Vinv
-//   schur_init / schur_blocks / schur_rhs       S = Hpp + lambda I - sum Y W^T (wave per 6x6 block,
-//                60 lanes = 5 pair slices x 12 three-element strips), gs = gp - sum Y gl
-//   chol_panel / chol_trsm / chol_update / chol_backsolve   block-band Cholesky, 8-pose panels;
-//                the trailing SYRK update runs on v_mfma_f64_16x16x4_f64
+//   schur_init / schur_rows / schur_rhs   S = Hpp + lambda I - sum Y W^T (one workgroup per block row, the
+//                row's Y resident in LDS, W rows gathered per co-observation pair), gs = gp - sum Y gl
+//                (schur_mfma: the same contraction on v_mfma_f64_4x4x4, kept as the measured alternative)
+//   chol_panel (panel 0) / chol_trsm_update (one launch per 8-pose panel: MFMA block substitution of the two
+//                row tiles a 48x48 update tile needs, SYRK on v_mfma_f64_16x16x4_f64, tile (0,0) goes on
+//                to factor the next panel) / chol_backsolve (cooperative, flag-ordered)
 //   backsub      wave / point      dl = -Vinv (gl + sum W^T dp)
 //   retract, eval_points, error_points, reduce_partials
+#include <cstdlib>
+#include <mutex>
 #include "vus_common.h"
 
 namespace {
@@ -1099,20 +1106,25 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
 //   workgroup g >= 1 waits for x_p, multiplies it with the blocks L(panel p, panel p - g - 1)^T --
 //     transposed on write-back, so an output reads one contiguous 48-byte block row -- and adds the
 //     result to y with f64 atomics.  Its operands are loaded one panel ahead of the x it waits for.
-// Flags (agent-scope release/acquire): F[0] = panels solved, F[1] = abort, F[2 + g] = panels done by
+// Flags (agent-scope atomics, see below): F[0] = panels solved, F[1] = abort, F[2 + g] = panels done by
 // workgroup g.  Every wait is bounded: a wait that expires raises the abort flag, all loops drain and
 // status = -1.  Only every 8th block of the grid works, which places all of them on one XCD (one L2).
 constexpr int BS_MAX_RHS = 8;
 constexpr int CB_THREADS = 512;          // 8 solver waves at most; threads < 8 * 48 = (panel row kk, output 6a + c)
 constexpr int CB_SPIN_LIMIT = 1 << 22;
 #ifndef VUS_CB_MAX_WG
-#define VUS_CB_MAX_WG 96
+#define VUS_CB_MAX_WG 1024
 #endif
 constexpr int CB_MAX_WG = VUS_CB_MAX_WG;    // solver + helpers
 
-// Data that crosses workgroups (x, y, the flags) is only touched with agent-scope atomics, which are
-// performed at the coherence point themselves; ordering is program order + s_waitcnt vmcnt(0) before a
-// flag is raised.  No __threadfence(): its L2 write-back / invalidate costs ~10 us per panel here.
+// Inter-workgroup protocol (MI355X_MICROARCH.md, "Valid forms": 8-byte agent-scope atomics on BOTH sides):
+// every word that crosses workgroups (x, y, the flags) is written and read ONLY with agent-scope atomic
+// stores / loads / adds, which are performed at the coherence point (sc1: they bypass the reader's L1 and
+// are never left dirty in a non-coherent cache); a producer drains its own vector-memory operations
+// (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, THEN one lane raises the flag; a consumer polls the
+// flag with relaxed sc1 loads from one lane, the workgroup meets at a barrier, and only then are the words
+// loaded (again sc1).  The factor L itself was written by earlier KERNELS and is read with plain loads.
+// No __threadfence(): its L2 write-back / invalidate costs ~10 us per panel here and orders nothing more.
 __device__ __forceinline__ int cb_load(const int* f) { return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void cb_drain() {   // every vector-memory operation of this wave has completed
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -1493,12 +1505,49 @@ extern "C" int vus_ba_add_diag(double* Sband, int n_poses, int band, double valu
 }
 
 namespace {
-// band == 0 has no spare slot in Sband: the solver runs alone and only touches F[0], F[1]; a process-wide
-// 16-int device buffer serves (allocated once).
-int* flags_fallback(hipStream_t) {
-  static int* buf = nullptr;
-  if (!buf && hipMalloc(&buf, 16 * sizeof(int)) != hipSuccess) buf = nullptr;
-  return buf;
+// band == 0 has no spare slot in Sband: the solver runs alone and only touches F[0], F[1]; one 16-int buffer per
+// DEVICE serves (allocated once, under a lock; concurrent band-0 solves may share it: nobody waits on F[0] when
+// there are no helpers, and F[1] is only ever raised by an expired wait, which a band-0 solve does not have).
+int* flags_fallback() {
+  static std::mutex mu;
+  static int* buf[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!buf[dev] && hipMalloc(&buf[dev], 16 * sizeof(int)) != hipSuccess) buf[dev] = nullptr;
+  return buf[dev];
+}
+
+// Number of workgroups of the cooperative back-substitution that are guaranteed to be co-resident even if the
+// dispatcher puts every working block (blockIdx % 8 == 0) on ONE XCD: the occupancy query for this kernel times
+// the compute units of one XCD, less a margin of one workgroup per four CUs (the query can read one block per
+// CU high, MI355X_MICROARCH.md "Residency and cooperative launch").  VUS_CB_MAX_WG (compile time) and the
+// environment variable of the same name (run time, used by the tests to force several row groups per
+// workgroup) cap it further.
+int backsolve_max_wg() {
+  static std::mutex mu;
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 1;
+  int cap;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!cached[dev]) {
+      int per_cu = 0, n_cu = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_backsolve_kernel, CB_THREADS, 0) != hipSuccess) per_cu = 1;
+      if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 8;
+      const int cu_xcd = n_cu >= 8 ? n_cu / 8 : 1;
+      int c = per_cu * cu_xcd - cu_xcd / 4;
+      cached[dev] = c < 1 ? 1 : c;
+    }
+    cap = cached[dev];
+  }
+  if (cap > CB_MAX_WG) cap = CB_MAX_WG;
+  if (const char* e = getenv("VUS_CB_MAX_WG")) {
+    const int v = atoi(e);
+    if (v >= 1 && v < cap) cap = v;
+  }
+  return cap;
 }
 
 int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, int* status, hipStream_t st) {
@@ -1524,12 +1573,13 @@ int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, 
   }
   // flags of the cooperative sweep live in the unused slots of block row 0 (blocks (0, k < 0))
   const int n_groups = band > 0 ? (band + PB - 1) / PB : 1;
-  int* F = band > 0 ? reinterpret_cast<int*>(Sband + 36) : flags_fallback(st);
+  int* F = band > 0 ? reinterpret_cast<int*>(Sband + 36) : flags_fallback();
   VUS_REQUIRE(F != nullptr, "no scratch for the solver flags");
   VUS_REQUIRE(band == 0 || 2 + n_groups <= 72 * band, "band=%d: too many row groups for the flag area", band);
   VUS_CHECK_HIP(hipMemsetAsync(F, 0, sizeof(int) * (size_t)(2 + n_groups), st));
-  // at most CB_MAX_WG cooperating workgroups (all resident on one XCD: 32 CUs x 4 workgroups of 512 threads)
-  const int n_wg = n_groups < CB_MAX_WG ? n_groups : CB_MAX_WG;
+  // at most backsolve_max_wg() cooperating workgroups, so that all of them are resident at once
+  const int max_wg = backsolve_max_wg();
+  const int n_wg = n_groups < max_wg ? n_groups : max_wg;
   chol_backsolve_kernel<<<8 * n_wg, CB_THREADS, 0, st>>>(Sband, n_nodes, band, y, ystride, n_rhs, n_groups, F, status);
   VUS_CHECK_LAUNCH("ba_band_solve");
   return VUS_OK;

@@ -25,7 +25,7 @@
 //    choice, and the descriptor words come straight out of __ballot (lane = test bit);
 //  * hamming_match keeps the train descriptors in LDS (broadcast reads) and one query per lane.
 #include "vus_common.h"
-#define VUS_TABLE_QUAL __device__ const
+#define VUS_TABLE_QUAL __device__ constexpr
 #include "../../include/vus_orb_tables.h"
 
 namespace {
@@ -534,16 +534,22 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
 __device__ const uint8_t kDiscUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 // Rotated test pattern re-laid for the kernel: [bin][lane][word] = the two patch byte offsets
-// (y * row bytes + x, int16 each) of test 64 * word + lane.  Filled once per device from VUS_RBRIEF_ROT.
-__device__ __attribute__((aligned(16))) uint32_t g_rot_off[VUS_N_ANGLE_BINS * 64 * 4];
-__global__ void rot_table_init_kernel() {
-  const int e = blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= VUS_N_ANGLE_BINS * 256) return;
-  const int bin = e / 256, test = e - 256 * bin, w = test >> 6, lane = test & 63;
-  const int8_t* t = VUS_RBRIEF_ROT + 4 * (size_t)e;
-  const int oa = t[1] * (4 * BR_DW) + t[0], ob = t[3] * (4 * BR_DW) + t[2];
-  g_rot_off[(bin * 64 + lane) * 4 + w] = ((uint32_t)oa & 0xFFFFu) | ((uint32_t)ob << 16);
+// (y * row bytes + x, int16 each) of test 64 * word + lane.  Derived from VUS_RBRIEF_ROT at COMPILE time, so
+// the table is part of the code object: no initialisation launch, nothing to order between streams or threads.
+struct RotOffTable {
+  uint32_t v[VUS_N_ANGLE_BINS * 64 * 4];
+};
+constexpr RotOffTable make_rot_off_table() {
+  RotOffTable r{};
+  for (int e = 0; e < VUS_N_ANGLE_BINS * 256; ++e) {
+    const int bin = e / 256, test = e - 256 * bin, w = test >> 6, lane = test & 63;
+    const int oa = VUS_RBRIEF_ROT[4 * e + 1] * (4 * BR_DW) + VUS_RBRIEF_ROT[4 * e];
+    const int ob = VUS_RBRIEF_ROT[4 * e + 3] * (4 * BR_DW) + VUS_RBRIEF_ROT[4 * e + 2];
+    r.v[(bin * 64 + lane) * 4 + w] = ((uint32_t)oa & 0xFFFFu) | ((uint32_t)ob << 16);
+  }
+  return r;
 }
+__device__ __attribute__((aligned(16))) const RotOffTable g_rot_off_table = make_rot_off_table();
 
 #ifndef VUS_OR_WPE
 #define VUS_OR_WPE 4
@@ -671,7 +677,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
       int bin = 31 - (int)(key & 31);
       bin = __builtin_amdgcn_readfirstlane(bin);
       // this lane's four tests of the bin's pattern, as patch byte offsets: one 16-byte load
-      const uint4 to = reinterpret_cast<const uint4*>(g_rot_off)[bin * 64 + lane];
+      const uint4 to = reinterpret_cast<const uint4*>(g_rot_off_table.v)[bin * 64 + lane];
       const uint8_t* c = blur8 + BR_R * (4 * BR_DW) + BR_R + sh_blur;   // the keypoint inside the patch
       const uint32_t tw[4] = {to.x, to.y, to.z, to.w};
       uint64_t word[4];
@@ -1359,17 +1365,6 @@ extern "C" int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_
   const int chunks = (max_kp + 4 * OR_KP_PER_WAVE - 1) / (4 * OR_KP_PER_WAVE);
   const long long blocks = (long long)((n_img + 7) / 8) * 8 * chunks;
   VUS_REQUIRE(blocks < (1ll << 31), "too many workgroups (%lld)", blocks);
-  {
-    static bool table_ready[64] = {};   // per device; a repeated initialisation writes the same values
-    int dev = 0;
-    VUS_CHECK_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !table_ready[dev]) {
-      rot_table_init_kernel<<<(VUS_N_ANGLE_BINS * 256 + 255) / 256, 256, 0, vus::as_stream(stream)>>>();
-      table_ready[dev] = true;
-    } else if (dev < 0 || dev >= 64) {
-      rot_table_init_kernel<<<(VUS_N_ANGLE_BINS * 256 + 255) / 256, 256, 0, vus::as_stream(stream)>>>();
-    }
-  }
   // rows of both planes on dword boundaries -> aligned patch loads; otherwise exact-start (unaligned) loads
   const bool aligned = ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(blur) | (uintptr_t)pitch |
                          (uintptr_t)W | ((uintptr_t)H * (uintptr_t)pitch)) & 3u) == 0;

@@ -7,8 +7,10 @@
 // (dims 3..5 are inert: unit diagonal, zero right-hand side); the shared bias B(0) is a 6-wide BORDER of
 // the reduced camera system, eliminated after the band solve with 7 right-hand sides.
 //
-// Everything is deterministic: factors are evaluated one per thread, their Hessian contributions are
-// added factor after factor by one workgroup (thread = one entry of the 24x24 block).
+// Factors are evaluated one per thread.  Their J^T J blocks on the camera side go in with f64 atomics (a block
+// receives at most two IMU factors, one DVL factor and one prior, so the sums differ between runs by the order of
+// at most four addends, ~1e-16 relative); the bias-bias block and the bias gradient, which every IMU factor
+// touches, are written per factor and reduced in a fixed order.
 #include "vus_common.h"
 
 namespace {

@@ -108,6 +108,35 @@ def allreduce_sum(t: torch.Tensor):
     return t
 
 
+def _collective(t: torch.Tensor, fn):
+    """Run an in-place collective on `t`; the gloo rehearsal stages GPU tensors through the host."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return t
+    if t.is_cuda and dist.get_backend() == "gloo":
+        h = t.cpu()
+        fn(h)
+        t.copy_(h)
+    else:
+        fn(t)
+    return t
+
+
+def allreduce_status(status: torch.Tensor):
+    """Worst band-solve status over the ranks, in place: the smallest one if any rank reports a negative code
+    (expired wait), else the largest (first non-positive pivot column + 1; 0 = ok)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return status
+    mn, mx = status.clone(), status.clone()
+    _collective(mn, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN))
+    _collective(mx, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX))
+    status.copy_(torch.where(mn < 0, mn, mx))
+    return status
+
+
+def broadcast_from_rank0(t: torch.Tensor):
+    return _collective(t, lambda x: dist.broadcast(x, src=0))
+
+
 class ShardedStereoBASolver:
     """Landmark-sharded LM: wraps a StereoBASolver built on this rank's observations (all poses, local
     landmarks, band forced to the global band) and inserts the collectives."""
@@ -164,6 +193,17 @@ def _make_shard_solver():
             if self.world > 1:
                 _lib.call("vus_ba_add_diag", _lib.ptr(self.Sband), self.P.n_poses, self.P.band,
                           -(self.world - 1) * float(lam), _lib.current_stream_ptr())
+
+        def band_solve(self):
+            super().band_solve()
+            if self.world > 1:
+                # The solve is replicated, but its cooperative back-substitution sums with f64 atomics: ranks
+                # would drift apart in the last bits.  Rank 0's dp is THE step on every rank, and a rank whose
+                # solve reported a problem (status < 0: bounded wait expired; > 0: non-positive pivot) makes
+                # every rank see it, so that all of them raise / reject together instead of one rank leaving
+                # its peers blocked in the next collective.
+                broadcast_from_rank0(self.dp)
+                allreduce_status(self.status)
 
         def eval_step(self, poses, points):
             super().eval_step(poses, points)

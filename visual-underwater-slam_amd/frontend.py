@@ -29,7 +29,9 @@ class ImageProcessorParams:
     max_disparity: int = 128
     stereo_max_distance: int = 64  # Hamming acceptance thresholds
     track_max_distance: int = 64
-    cand_cap: int = 32768          # candidate slots per image before top-K selection
+    cand_cap: int = 0              # candidate slots per image before top-K selection; 0 = sized from the image:
+                                   # max(32768, H*W/16) -- strict 3x3 NMS leaves at most H*W/4 candidates, the
+                                   # corner-dense bench texture ~H*W/37; an overflow is never silent (check_overflow)
     grid_row: int = 0              # stereo.launch:36-39 -- with grid_max_feature_num > 0 every cell of the
     grid_col: int = 0              # grid_row x grid_col grid keeps its grid_max_feature_num best corners
     grid_max_feature_num: int = 0  # (the nodelet's values: 3 x 4 cells, 4 per cell); 0 = global top max_features
@@ -112,6 +114,11 @@ class StereoOrbFrontend:
         _lib.require_gpu()
         _lib.load()
         self.p = params or ImageProcessorParams()
+        if self.p.cand_cap <= 0:
+            import dataclasses
+            self.p = dataclasses.replace(self.p, cand_cap=max(32768, (int(H) * int(W)) // 16))
+        self.stage_hook = None      # optional callable(name), called on the launch stream after every stage of
+                                    # process() (bench.py records HIP events there); None = no overhead
         if self.p.grid_max_feature_num > 0:
             assert self.p.grid_row >= 1 and self.p.grid_col >= 1 and self.p.n_levels == 1, \
                 "grid bucketing needs grid_row, grid_col >= 1 and a single pyramid level"
@@ -134,6 +141,9 @@ class StereoOrbFrontend:
         self.track_q, self.track_t = (2 * f).contiguous(), (2 * f + 2).contiguous()
         self.kp_level = self.kp_xy_q4 = None
         self.levels = None
+        # sticky device-side maximum of the per-image candidate counts since the last check_overflow(): a
+        # process(check=False) call that overflowed cand_cap is still reported by the next check
+        self.cand_max_seen = torch.zeros((1,), dtype=torch.int32, device=dev)
         if self.p.cross_check:   # backward pairings (same row layout as match_idx)
             self.rev_idx = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
             self.rev_dist = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
@@ -166,27 +176,35 @@ class StereoOrbFrontend:
         n_img = 2 * F
         st = _lib.current_stream_ptr()
         ptr = _lib.ptr
+        mark = self.stage_hook or (lambda name: None)
+        mark("begin")
         if self.levels is None:
             self.cand_count[:n_img].zero_()
             _lib.call("vus_fast_detect", ptr(images), n_img, H, W, W, p.fast_threshold, p.border,
                       ptr(self.blur), ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
+            mark("fast_detect")
             if p.grid_max_feature_num > 0:
                 _lib.call("vus_select_grid", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, H, W,
                           p.grid_row, p.grid_col, p.grid_max_feature_num, K, ptr(self.kp_keys), ptr(self.kp_count), st)
             else:
                 _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, K,
                           ptr(self.kp_keys), ptr(self.kp_count), st)
+            mark("select_topk")
             _lib.call("vus_orient_rbrief", ptr(images), ptr(self.blur), n_img, H, W, W, ptr(self.kp_keys),
                       ptr(self.kp_count), K, ptr(self.desc), ptr(self.angle), st)
+            mark("orient_rbrief")
         else:
             self._process_pyramid(images, n_img, st)
+            mark("pyramid_detect_describe")
         _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, H, W,
                   ptr(self.stereo_q), ptr(self.stereo_t), F, p.stereo_threshold, p.min_disparity,
                   p.max_disparity, p.stereo_max_distance, ptr(self.match_idx), ptr(self.match_dist), st)
+        mark("hamming_stereo")
         if F > 1:
             _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, H, W,
                       ptr(self.track_q), ptr(self.track_t), F - 1, -1, 0, 0, p.track_max_distance,
                       ptr(self.match_idx[self.max_frames:]), ptr(self.match_dist[self.max_frames:]), st)
+        mark("hamming_track")
         if p.cross_check:
             # backward pairings: right -> left under the mirrored disparity gate, left(t+1) -> left(t)
             _lib.call("vus_hamming_match", ptr(self.desc), ptr(self.kp_keys), ptr(self.kp_count), K, H, W,
@@ -199,6 +217,10 @@ class StereoOrbFrontend:
                           ptr(self.rev_idx[self.max_frames:]), ptr(self.rev_dist[self.max_frames:]), st)
                 _lib.call("vus_cross_check", ptr(self.match_idx[self.max_frames:]), ptr(self.rev_idx[self.max_frames:]),
                           F - 1, K, ptr(self.match_idx[self.max_frames:]), st)
+            mark("cross_check")
+        if self.levels is None:   # two tiny device ops, asynchronous: keeps an overflow visible to a later check
+            torch.maximum(self.cand_max_seen, self.cand_count[:n_img].max().reshape(1), out=self.cand_max_seen)
+        mark("end")
         if check:
             self.check_overflow(n_img)
         return FrontendResult(self, F)
@@ -229,14 +251,16 @@ class StereoOrbFrontend:
                       ptr(self.angle), ptr(self.kp_level), ptr(self.kp_xy_q4), st)
 
     def check_overflow(self, n_img=None):
+        """Raises if any image since the last check produced more FAST candidates than cand_cap (one device
+        read: synchronises the stream)."""
         if self.levels is not None:
             worst = int(self.pyr_cand_max.item())
             if worst > self.p.cand_cap:
                 raise _lib.VusError(f"FAST produced {worst} candidates in one pyramid level, more than cand_cap="
                                     f"{self.p.cand_cap}: raise ImageProcessorParams.cand_cap")
             return
-        n_img = self.cand_count.shape[0] if n_img is None else n_img
-        worst = int(self.cand_count[:n_img].max().item())
+        worst = int(self.cand_max_seen.item())
+        self.cand_max_seen.zero_()
         if worst > self.p.cand_cap:
             raise _lib.VusError(f"FAST produced {worst} candidates in one image, more than cand_cap="
                                 f"{self.p.cand_cap}: raise ImageProcessorParams.cand_cap")
