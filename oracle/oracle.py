@@ -104,6 +104,15 @@ def orient_rbrief(img, blur, kp_keys, kp_count):
     return desc, ang
 
 
+def steering_tables(which=0):
+    """(rot int8 [30,256,4], cos_q14 int32 [30], sin_q14 int32 [30]).  which=0: derived by the oracle itself with
+    libm at load time (what vus_orient_rbrief_cpu uses); which=1: the generated header include/vus_orb_tables.h
+    (what the HIP kernels compile in)."""
+    rot = np.zeros((30, 256, 4), np.int8); c = np.zeros(30, np.int32); sn = np.zeros(30, np.int32)
+    _check(lib().vus_oracle_tables_cpu(int(which), _p(rot), _p(c), _p(sn)), "oracle_tables")
+    return rot, c, sn
+
+
 def resize_bilinear(img, Hd, Wd):
     img, n, H, W = _img_args(img)
     out = np.empty((n, Hd, Wd), np.uint8)

@@ -25,6 +25,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <math.h>
 #ifdef _OPENMP
 #include <omp.h>
 #endif
@@ -201,10 +202,54 @@ int vus_select_grid_cpu(const uint32_t* cand_keys, const int* cand_count, int n_
   return VUS_OK;
 }
 
+/* The oracle's OWN steering tables, derived here from first principles with libm and NOT read from the
+ * generated header the kernels compile in (include/vus_orb_tables.h: VUS_ANGLE_COS/SIN, VUS_RBRIEF_ROT), so
+ * that a wrong generated table cannot pass both sides (tests/test_frontend_oracle.py compares the two):
+ *   bin direction k: (cos, sin)(2 pi k / 30) in Q14, rounded to nearest (Rublee et al. 2011, sec. 4.2:
+ *   "discretize the angle to increments of 2 pi / 30 (12 degrees)");
+ *   rotated test point: (x cos - y sin, x sin + y cos), each rounded half-to-even (rint), of the 256 learned
+ *   pairs VUS_RBRIEF_BASE (third-party DATA: the published rBRIEF table). */
+static int32_t g_cos_q14[VUS_N_ANGLE_BINS], g_sin_q14[VUS_N_ANGLE_BINS];
+static int8_t g_rot[VUS_N_ANGLE_BINS * 256 * 4];
+static int g_tables_ready = 0;
+
+static void oracle_tables_init(void) {
+  if (g_tables_ready) return;
+#pragma omp critical(vus_oracle_tables)
+  if (!g_tables_ready) {
+    const double two_pi = 6.283185307179586476925286766559;
+    for (int k = 0; k < VUS_N_ANGLE_BINS; ++k) {
+      const double th = two_pi * (double)k / (double)VUS_N_ANGLE_BINS;
+      const double c = cos(th), sn = sin(th);
+      g_cos_q14[k] = (int32_t)rint(c * 16384.0);
+      g_sin_q14[k] = (int32_t)rint(sn * 16384.0);
+      for (int t = 0; t < 256; ++t)
+        for (int h = 0; h < 4; h += 2) {
+          const double x = (double)VUS_RBRIEF_BASE[4 * t + h], y = (double)VUS_RBRIEF_BASE[4 * t + h + 1];
+          g_rot[((size_t)k * 256 + t) * 4 + h] = (int8_t)rint(x * c - y * sn);
+          g_rot[((size_t)k * 256 + t) * 4 + h + 1] = (int8_t)rint(x * sn + y * c);
+        }
+    }
+    g_tables_ready = 1;
+  }
+}
+
+/* which = 0: the oracle's derived tables; 1: the generated header's (what the kernels use).  For the test
+ * that compares them.  rot [30*256*4] int8, cosq/sinq [30] int32. */
+int vus_oracle_tables_cpu(int which, int8_t* rot, int32_t* cosq, int32_t* sinq) {
+  if (!rot || !cosq || !sinq) return VUS_E_INVALID;
+  oracle_tables_init();
+  memcpy(rot, which ? VUS_RBRIEF_ROT : g_rot, sizeof(g_rot));
+  memcpy(cosq, which ? VUS_ANGLE_COS : g_cos_q14, sizeof(g_cos_q14));
+  memcpy(sinq, which ? VUS_ANGLE_SIN : g_sin_q14, sizeof(g_sin_q14));
+  return VUS_OK;
+}
+
 int vus_orient_rbrief_cpu(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
                           const uint32_t* kp_keys, const int* kp_count, int max_kp,
                           uint64_t* desc_out, uint8_t* angle_out) {
   if (!img || !blur || !kp_keys || !kp_count || !desc_out || !angle_out) return VUS_E_INVALID;
+  oracle_tables_init();
 #pragma omp parallel for schedule(dynamic)
   for (int n = 0; n < n_img; ++n) {
     const uint8_t* im = img + (size_t)n * H * pitch;
@@ -225,13 +270,13 @@ int vus_orient_rbrief_cpu(const uint8_t* img, const uint8_t* blur, int n_img, in
       }
       /* nearest of the 30 bin directions = largest projection; first maximum wins */
       int bin = 0;
-      int64_t best = m10 * VUS_ANGLE_COS[0] + m01 * VUS_ANGLE_SIN[0];
+      int64_t best = m10 * g_cos_q14[0] + m01 * g_sin_q14[0];
       for (int k = 1; k < VUS_N_ANGLE_BINS; ++k) {
-        int64_t pr = m10 * VUS_ANGLE_COS[k] + m01 * VUS_ANGLE_SIN[k];
+        int64_t pr = m10 * g_cos_q14[k] + m01 * g_sin_q14[k];
         if (pr > best) { best = pr; bin = k; }
       }
       angle_out[(size_t)n * max_kp + i] = (uint8_t)bin;
-      const int8_t* pat = VUS_RBRIEF_ROT + (size_t)bin * 256 * 4;
+      const int8_t* pat = g_rot + (size_t)bin * 256 * 4;
       for (int t = 0; t < 256; ++t) {
         int a = bl[clampi(y + pat[4 * t + 1], 0, H - 1) * W + clampi(x + pat[4 * t + 0], 0, W - 1)];
         int b = bl[clampi(y + pat[4 * t + 3], 0, H - 1) * W + clampi(x + pat[4 * t + 2], 0, W - 1)];

@@ -309,3 +309,22 @@ def test_track_ids_semantics(oracle):
     # batch.py:152-154 maps the normalised coordinates back to pixels of ITS resolution convention
     uL = (feat[0, 0, 0] + 1) * 0.5 * W
     assert np.isclose(uL, x0)
+
+
+def test_oracle_steering_tables_are_derived_independently_and_agree_with_the_kernels_header(oracle):
+    """The oracle builds its 30 bin directions and the 30 rotated copies of the 256 learned test pairs itself
+    (libm cos/sin + rint at load time); the HIP kernels use the generated header.  Both must agree, and both
+    must agree with a third derivation in numpy -- a wrong generated table can no longer pass both sides."""
+    rot_o, c_o, s_o = oracle.steering_tables(0)
+    rot_h, c_h, s_h = oracle.steering_tables(1)
+    assert np.array_equal(rot_o, rot_h) and np.array_equal(c_o, c_h) and np.array_equal(s_o, s_h)
+    th = 2.0 * np.pi * np.arange(30) / 30
+    assert np.array_equal(np.rint(np.cos(th) * 16384).astype(np.int32), c_h)
+    assert np.array_equal(np.rint(np.sin(th) * 16384).astype(np.int32), s_h)
+    base = rot_h[0].astype(np.float64)                     # bin 0 = the unrotated learned pairs
+    for k in range(30):
+        a, b = np.cos(th[k]), np.sin(th[k])
+        for h in (0, 2):
+            assert np.array_equal(np.rint(base[:, h] * a - base[:, h + 1] * b), rot_h[k, :, h])
+            assert np.array_equal(np.rint(base[:, h] * b + base[:, h + 1] * a), rot_h[k, :, h + 1])
+    assert np.abs(rot_h).max() <= 18                       # VUS_RBRIEF_REACH: the 37x37 smoothed patch covers it
