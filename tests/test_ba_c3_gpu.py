@@ -1,0 +1,155 @@
+"""BASELINE.json configs[2] at FULL size through the HIP path: 2000 keyframes x 50k landmarks (48,299 observed),
+1.93 M stereo factors, band 224 pose blocks (28 cooperating row groups in the back-substitution).
+
+The scalar oracle cannot run the whole problem in test time, so parity at this size is established on
+SUB-PROBLEMS whose oracle results equal the corresponding slices of the full problem exactly:
+  * a random 1 % of the landmarks with ALL their observations  ->  V, gl, W rows of those landmarks;
+  * a handful of poses with every landmark they see and ALL observations of those landmarks
+       ->  Hpp, gp, gs and the complete block rows of the reduced camera system (Sband) of those poses;
+and through size-independent properties: the linear solve leaves a residual |S dp + gs| <= 1e-9 |gs| (checked with
+plain torch fp64 band mat-vec), status 0, every LM trial accepted with monotone error, ground truth recovered.
+Reference call site: gtsam.LevenbergMarquardtOptimizer(...).optimize(), /root/reference/batch.py:337."""
+import numpy as np
+import pytest
+import torch
+
+from visual_underwater_slam_amd import synth, ba_pack
+
+pytestmark = pytest.mark.gpu
+
+N_KF, N_LM, OBS = 2000, 50000, 1000
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, float), np.asarray(b, float)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+
+
+@pytest.fixture(scope="module")
+def c3(gpu):
+    from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
+    s = synth.ba_sequence(N_KF, N_LM, OBS)
+    nL = len(s["points_gt"])
+    prob = StereoBAProblem(s["obs_pose"], s["obs_point"], s["meas"], N_KF, nL, s["K"], s["sigma"],
+                           prior_pose=[0], prior_T=s["poses_gt"][:1], prior_sigmas=s["prior_sigmas"][None])
+    return s, prob, StereoBASolver(prob)
+
+
+def sub_problem(oracle, s, mask):
+    """Oracle problem of the observations selected by `mask` (all poses kept, landmarks renumbered compactly).
+    Returns (P, pk, used_landmarks)."""
+    used = np.unique(s["obs_point"][mask])
+    remap = -np.ones(len(s["points_gt"]), np.int64)
+    remap[used] = np.arange(len(used))
+    pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"][mask]), torch.from_numpy(remap[s["obs_point"][mask]]),
+                                   torch.from_numpy(s["meas"][mask]), N_KF, len(used))
+    P = oracle.BAProblem(pk, s["K"], s["sigma"], (np.array([0], np.int32), s["poses_gt"][:1], s["prior_sigmas"][None]))
+    return P, pk, used
+
+
+def test_c3_has_the_baseline_size(c3):
+    s, prob, sv = c3
+    assert prob.n_poses == 2000 and 45000 < prob.n_points <= 50000 and 1.8e6 < prob.n_obs <= 2.0e6
+    assert prob.band >= 200 and prob.st["n_pairs"] > 5e7
+
+
+def test_c3_linearisation_matches_oracle_on_a_landmark_sample(c3, oracle):
+    s, prob, sv = c3
+    sv.linearize(torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda())
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(5)
+    sel = np.sort(rng.choice(prob.n_points, prob.n_points // 100, replace=False))
+    mask = np.isin(s["obs_point"], sel)
+    P, pk, used = sub_problem(oracle, s, mask)
+    assert np.array_equal(used, sel)
+    lin = oracle.ba_linearize(P, s["poses_init"], s["points_init"][sel])
+    assert relerr(sv.V.cpu().numpy()[sel], lin["V"]) < 1e-11
+    assert relerr(sv.gl.cpu().numpy()[sel], lin["gl"]) < 1e-11
+    # W rows: the sequence is sorted by (point, pose), so L-order index == sequence index on both sides
+    assert bool((prob.pk["perm"].cpu() == torch.arange(prob.n_obs)).all())
+    full_slot = prob.pk["obs_ppos"].cpu().numpy()[np.nonzero(mask)[0]]
+    sub_slot = pk["obs_ppos"].numpy()
+    assert relerr(sv.W.cpu().numpy()[full_slot], lin["W"][sub_slot]) < 1e-11
+
+
+@pytest.mark.parametrize("lam", [1e-5, 10.0])
+def test_c3_reduced_camera_rows_match_oracle_on_a_pose_sample(c3, oracle, lam):
+    s, prob, sv = c3
+    sv.linearize(torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda())
+    sv.schur(lam)
+    torch.cuda.synchronize()
+    rows = np.array([0, 1, 777, 1203, 1999])
+    seen = np.unique(s["obs_point"][np.isin(s["obs_pose"], rows)])
+    mask = np.isin(s["obs_point"], seen)                 # every observation of every landmark those poses see
+    P, pk, used = sub_problem(oracle, s, mask)
+    lin = oracle.ba_linearize(P, s["poses_init"], s["points_init"][used])
+    sch = oracle.ba_schur(P, prob.band, lam, lin)
+    assert relerr(sv.Hpp.cpu().numpy()[rows], lin["Hpp"][rows]) < 1e-11
+    assert relerr(sv.gp.cpu().numpy()[rows], lin["gp"][rows]) < 1e-11
+    assert relerr(sv.gs.cpu().numpy()[rows], sch["gs"][rows]) < 1e-10
+    Sg = sv.Sband.cpu().numpy()[rows]
+    assert relerr(Sg, sch["Sband"][rows]) < 1e-10
+    assert np.abs(Sg[2, 1:60]).max() > 0                 # the sampled rows do have off-diagonal blocks
+
+
+def band_matvec(Sband, x):
+    """y = S x for the symmetric block band (lower blocks stored), plain torch fp64."""
+    n, B1 = Sband.shape[0], Sband.shape[1]
+    blk = Sband.view(n, B1, 6, 6)
+    y = torch.zeros_like(x)
+    for sft in range(B1):
+        if sft >= n:
+            break
+        lo = blk[sft:, sft]                               # blocks (i, i - sft), i >= sft
+        y[sft:] += torch.einsum("irc,ic->ir", lo, x[:n - sft])
+        if sft > 0:
+            y[:n - sft] += torch.einsum("irc,ir->ic", lo, x[sft:])
+    return y
+
+
+def test_c3_band_solve_residual_and_status(c3):
+    s, prob, sv = c3
+    sv.linearize(torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda())
+    for lam in (1e-5, 1.0):
+        sv.schur(lam)
+        S0 = sv.Sband.clone()
+        F = S0.view(prob.n_poses, prob.band + 1, 36)
+        sv.band_solve()
+        torch.cuda.synchronize()
+        assert int(sv.status.item()) == 0
+        res = band_matvec(S0, sv.dp) + sv.gs
+        assert float(res.abs().max() / sv.gs.abs().max()) < 1e-9, lam
+
+
+def test_c3_full_lm_converges_to_ground_truth(c3):
+    s, prob, sv = c3
+    poses, points, rep = sv.optimize(torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda())
+    assert rep.status == 0 and rep.tries == rep.outer == rep.iterations      # every trial accepted, band solve ok
+    hist = [rep.initial_error] + rep.err_hist
+    assert all(b <= a for a, b in zip(hist, hist[1:]))                        # monotone
+    assert rep.final_error < 1e-3 * rep.initial_error
+    assert np.abs(poses.cpu().numpy()[:, 9:] - s["poses_gt"][:, 9:]).max() < 0.02
+    assert np.median(np.abs(points.cpu().numpy() - s["points_gt"])) < 0.02
+
+
+def test_c3_through_the_gtsam_shaped_boundary(c3):
+    """The drop-in call of batch.py:337 at the BASELINE size: graph with one bulk StereoFactorBlock
+     -> same optimum as the array-level solver."""
+    import visual_underwater_slam_amd.gtsam as gtsam
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import X, L
+    s, prob, sv = c3
+    graph, initial = gtsam.NonlinearFactorGraph(), gtsam.Values()
+    graph.add(gtsam.PriorFactorPose3(X(0), gtsam.Pose3.from_flat12(s["poses_gt"][0]),
+                                     gtsam.noiseModel.Diagonal.Sigmas(s["prior_sigmas"])))
+    graph.push_back(gtsam.StereoFactorBlock(s["meas"], gtsam.noiseModel.Isotropic.Sigma(3, s["sigma"]),
+                                            X(0) + s["obs_pose"].astype(np.int64), L(0) + s["obs_point"].astype(np.int64),
+                                            gtsam.Cal3_S2Stereo(*s["K"])))
+    initial.insert_pose3_block(X(0) + np.arange(N_KF, dtype=np.int64), s["poses_init"])
+    initial.insert_point3_block(L(0) + np.arange(prob.n_points, dtype=np.int64), s["points_init"])
+    opt = gtsam.LevenbergMarquardtOptimizer(graph, initial, gtsam.LevenbergMarquardtParams())
+    res = opt.optimize()
+    poses, points, rep = sv.optimize(torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda())
+    got = res.pose3_block(X(0) + np.arange(N_KF, dtype=np.int64))
+    assert relerr(got, poses.cpu().numpy()) < 1e-9
+    assert opt.iterations() == rep.iterations and np.isclose(opt.error(), rep.final_error, rtol=1e-9)
+    assert np.allclose(res.atPose3(X(1234)).flat12(), got[1234])             # object read-back, batch.py:57-68

@@ -222,3 +222,51 @@ def test_gtsam_shaped_optimize_is_a_drop_in(gpu, oracle):
                                          gtsam.Cal3_S2Stereo(*seq["K"])))
     r2 = gtsam.LevenbergMarquardtOptimizer(g2, initial, gtsam.LevenbergMarquardtParams()).optimize()
     assert relerr(np.stack([r2.atPose3(X(i)).flat12() for i in range(50)]), got) < 1e-12
+
+
+def test_band_solve_with_several_row_groups_per_workgroup(gpu, oracle, monkeypatch):
+    """Bands wider than the resident workgroup count give one workgroup several row groups of the cooperative
+    back-substitution.  VUS_CB_MAX_WG=3 forces that path on small systems (solver + 2 helpers serving up to 12
+    row groups); answers must equal numpy's dense solve, status 0."""
+    from visual_underwater_slam_amd import _lib
+    monkeypatch.setenv("VUS_CB_MAX_WG", "3")
+    rng = np.random.default_rng(7)
+    for nP, B in [(64, 63), (131, 37), (200, 90), (97, 8), (260, 17)]:
+        n = 6 * nP
+        A = np.zeros((n, n))
+        for i in range(nP):
+            for k in range(max(0, i - B), i + 1):
+                A[6 * i:6 * i + 6, 6 * k:6 * k + 6] = rng.normal(size=(6, 6))
+        A = np.tril(A) + np.tril(A, -1).T
+        A += np.eye(n) * (np.abs(A).sum(1).max() + 1.0)
+        Sb = np.zeros((nP, B + 1, 36))
+        for i in range(nP):
+            for k in range(max(0, i - B), i + 1):
+                Sb[i, i - k] = A[6 * i:6 * i + 6, 6 * k:6 * k + 6].reshape(-1)
+        gs = rng.normal(size=(nP, 6))
+        d_S = torch.from_numpy(Sb).cuda(); d_g = torch.from_numpy(gs).cuda()
+        d_x = torch.empty((nP, 6), dtype=torch.float64, device="cuda")
+        d_st = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.call("vus_ba_band_solve", d_S.data_ptr(), nP, B, d_g.data_ptr(), d_x.data_ptr(), d_st.data_ptr(),
+                  _lib.current_stream_ptr())
+        assert int(d_st.item()) == 0
+        assert relerr(d_x.cpu().numpy().reshape(-1), np.linalg.solve(A, -gs.reshape(-1))) < 1e-10, (nP, B)
+    # ... and the seven-right-hand-side form the inertial graphs use
+    nP, B = 90, 40
+    n = 6 * nP
+    A = np.zeros((n, n))
+    for i in range(nP):
+        for k in range(max(0, i - B), i + 1):
+            A[6 * i:6 * i + 6, 6 * k:6 * k + 6] = rng.normal(size=(6, 6))
+    A = np.tril(A) + np.tril(A, -1).T
+    A += np.eye(n) * (np.abs(A).sum(1).max() + 1.0)
+    Sb = np.zeros((nP, B + 1, 36))
+    for i in range(nP):
+        for k in range(max(0, i - B), i + 1):
+            Sb[i, i - k] = A[6 * i:6 * i + 6, 6 * k:6 * k + 6].reshape(-1)
+    rhs = rng.normal(size=(7, n))
+    d_S = torch.from_numpy(Sb).cuda(); d_r = torch.from_numpy(rhs).cuda()
+    d_st = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.call("vus_ba_band_solve_multi", d_S.data_ptr(), nP, B, d_r.data_ptr(), 7, d_st.data_ptr(), _lib.current_stream_ptr())
+    assert int(d_st.item()) == 0
+    assert relerr(d_r.cpu().numpy(), np.linalg.solve(A, rhs.T).T) < 1e-10

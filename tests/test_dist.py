@@ -162,3 +162,52 @@ def test_sharded_lm_two_ranks_on_one_gpu_matches_single(gpu):
         assert np.abs(p - poses.cpu().numpy()).max() < 1e-9 * max(1.0, np.abs(p).max())     # 1e-9 rel
         assert np.abs(pt - points.cpu().numpy()).max() < 1e-8 * np.abs(pt).max()
     assert np.array_equal(out[0][0], out[1][0])
+
+
+def _status_worker(rank, world):
+    st = torch.tensor([0 if rank == 0 else -1], dtype=torch.int32)
+    vdist.allreduce_status(st)
+    st2 = torch.tensor([0 if rank == 0 else 58], dtype=torch.int32)
+    vdist.allreduce_status(st2)
+    x = torch.full((4,), float(rank + 1), dtype=torch.float64)
+    vdist.broadcast_from_rank0(x)
+    return int(st[0]), int(st2[0]), x.tolist()
+
+
+def test_status_agreement_and_step_broadcast_gloo_world2():
+    """A rank whose band solve gave up (-1) or met a non-positive pivot (k+1) makes EVERY rank see it, and rank 0's
+    step is the step on every rank (the replicated solve sums with f64 atomics: last bits differ between ranks)."""
+    out = _run(_status_worker, 2)
+    for r in range(2):
+        assert out[r] == (-1, 58, [1.0, 1.0, 1.0, 1.0])
+
+
+def _frontend_shard_worker(rank, world, n_frames, H, W, K):
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    torch.cuda.set_device(0)
+    first, n_owned, n_halo = vdist.shard_frames(n_frames, world, rank)
+    img = torch.from_numpy(synth.stereo_frames(first, n_halo, H=H, W=W)).cuda()
+    fe = StereoOrbFrontend(H, W, max_frames=n_halo, params=ImageProcessorParams(max_features=K))
+    res = fe.process(img)
+    s, t, k = vdist.gather_tracks(*vdist.owned_track_records(res, n_owned), n_frames, world, rank)
+    return s.cpu().numpy(), t.cpu().numpy(), k.cpu().numpy()
+
+
+@pytest.mark.gpu
+def test_frame_sharded_frontend_two_ranks_on_one_gpu_equals_unsharded(gpu):
+    """BASELINE.json configs[3] rehearsed on the one visible GPU: each rank runs the real StereoOrbFrontend on its
+    shard_frames() range plus the one-frame halo, gather_tracks() assembles the stream's records; bit-identical
+    to the unsharded run (stereo matches, temporal matches across the shard boundary, keypoint keys)."""
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    n_frames, H, W, K = 7, 240, 320, 400
+    out = _run(_frontend_shard_worker, 2, n_frames, H, W, K)
+    img = torch.from_numpy(synth.stereo_frames(0, n_frames, H=H, W=W)).cuda()
+    fe = StereoOrbFrontend(H, W, max_frames=n_frames, params=ImageProcessorParams(max_features=K))
+    res = fe.process(img)
+    stereo, keys = res.stereo_idx.cpu().numpy(), res.kp_keys[0::2].cpu().numpy()
+    track = np.full((n_frames, K), -1, np.int32)
+    track[:n_frames - 1] = res.track_idx.cpu().numpy()
+    assert (track[:-1] >= 0).sum() > 100 and (stereo >= 0).sum() > 100
+    for r in range(2):
+        s, t, k = out[r]
+        assert np.array_equal(s, stereo) and np.array_equal(t, track) and np.array_equal(k, keys)

@@ -211,3 +211,48 @@ def test_reporting_helpers_follow_batch_py():
     odom = pos + np.array([0.0, 0.0, 0.7433])            # batch.py:363
     assert report.trajectory_mse(pts, odom) < 1e-30
     assert np.isclose(report.trajectory_mse(pts, odom + 0.1), 0.01)
+
+
+def test_values_array_blocks_behave_like_individually_inserted_variables():
+    """EXTENSION: Values.insert_point3_block / insert_pose3_block keep whole runs as arrays (the vectorised
+    batch.py:297-298); every gtsam accessor sees them exactly as if they had been inserted one by one."""
+    seq = synth.ba_sequence(6, 40, 12)
+    nL = len(seq["points_gt"])
+    a, b = Values(), Values()
+    for i in range(6):
+        a.insert(X(i), Pose3.from_flat12(seq["poses_init"][i]))
+    for j in range(nL):
+        a.insert(L(j), seq["points_init"][j])
+    perm = np.random.default_rng(0).permutation(nL)                    # any key order is accepted
+    b.insert_pose3_block([X(i) for i in range(6)], seq["poses_init"])
+    b.insert_point3_block([L(int(j)) for j in perm], seq["points_init"][perm])
+    assert a.keys() == b.keys() and a.size() == b.size() == 6 + nL
+    assert b.exists(L(3)) and not b.exists(L(nL)) and b.exists(X(5)) and not b.exists(V(0))
+    assert np.array_equal(b.atPoint3(L(7)), a.atPoint3(L(7))) and np.array_equal(b.atVector(L(7)), a.atVector(L(7)))
+    assert b.atPose3(X(2)).equals(a.atPose3(X(2)), 0.0)
+    assert np.array_equal(b.point3_block([L(5), L(0)]), seq["points_init"][[5, 0]])
+    assert np.array_equal(a.point3_block([L(5), L(0)]), seq["points_init"][[5, 0]])      # bulk read of dict entries
+    assert np.array_equal(a.pose3_block([X(1)]), b.pose3_block([X(1)]))
+    with pytest.raises(RuntimeError, match="already exists"):
+        b.insert(L(3), np.zeros(3))
+    with pytest.raises(RuntimeError, match="already exists"):
+        b.insert_point3_block([L(nL), L(2)], np.zeros((2, 3)))
+    with pytest.raises(RuntimeError, match="does not exist"):
+        b.point3_block([L(nL + 5)])
+    with pytest.raises(RuntimeError):
+        b.atPose3(L(1))                                                 # wrong type, like gtsam
+    c = Values(b)                                                       # copies are independent
+    c.update(L(3), np.array([1.0, 2.0, 3.0]))
+    c.update(X(3), Pose3())
+    assert c.atPoint3(L(3)).tolist() == [1.0, 2.0, 3.0] and np.array_equal(b.atPoint3(L(3)), a.atPoint3(L(3)))
+    assert c.atPose3(X(3)).equals(Pose3(), 0.0) and not b.atPose3(X(3)).equals(Pose3(), 1e-9)
+    c.erase(L(3))
+    assert not c.exists(L(3)) and c.size() == b.size() - 1 and b.exists(L(3))
+    # the optimizer's packing does not care how the variables were inserted
+    graph, _ = mini_batch_create(seq)
+    for k in (B(0), *[V(i) for i in range(6)]):
+        b.insert(k, gtsam.imuBias.ConstantBias() if k == B(0) else np.zeros(3))
+    _, full = mini_batch_create(seq)
+    pa, pb = _pack_graph(graph, full), _pack_graph(graph, b)
+    for name in ("meas", "pose_idx", "lm_idx", "pose_keys", "lm_keys", "poses", "points"):
+        assert np.array_equal(pa[name], pb[name]), name

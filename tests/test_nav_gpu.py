@@ -225,3 +225,38 @@ def test_batch_py_full_graph_through_the_gtsam_shaped_api(gpu, oracle):
     graph.push_back(gtsam.CustomFactor(gtsam.noiseModel.Isotropic.Sigma(3, 0.1), [V(1), X(1)], lambda *a: None))
     with pytest.raises(NotImplementedError, match="DvlVelocityFactor"):
         gtsam.LevenbergMarquardtOptimizer(graph, initial, gtsam.LevenbergMarquardtParams()).optimize()
+
+
+def drop_keyframe0_observations(seq):
+    """The reference never emits stereo factors for keyframe 0 (batch.py:280-305: the landmark loop sits in the
+    `else` of `i == 0`), so X(0) is tied to the rest of the graph only through the ImuFactor X(0)-X(1), its prior and
+    V(0)'s prior.  Same sequence with keyframe 0's observations removed and the landmarks renumbered compactly."""
+    keep = seq["obs_pose"] != 0
+    used = np.unique(seq["obs_point"][keep])
+    remap = -np.ones(len(seq["points_gt"]), np.int64)
+    remap[used] = np.arange(len(used))
+    out = dict(seq)
+    out["obs_pose"] = seq["obs_pose"][keep]
+    out["obs_point"] = remap[seq["obs_point"][keep]].astype(seq["obs_point"].dtype)
+    out["meas"] = seq["meas"][keep]
+    out["points_gt"], out["points_init"] = seq["points_gt"][used], seq["points_init"][used]
+    return out
+
+
+def test_reference_topology_keyframe0_without_stereo_factors(gpu, oracle):
+    """batch.py's actual graph: no stereo factor touches X(0).  Through the gtsam-shaped API, against the oracle."""
+    import visual_underwater_slam_amd.gtsam as gtsam
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import B, V, X
+    seq = drop_keyframe0_observations(synth.nav_sequence(16, 400, 80))
+    assert (seq["obs_pose"] > 0).all()
+    graph, initial = batch_create_full(seq)
+    opt = gtsam.LevenbergMarquardtOptimizer(graph, initial, gtsam.LevenbergMarquardtParams())   # batch.py:337
+    results = opt.optimize()
+    P, N = build_nav(oracle, seq, zero_velocity_prior=True)
+    op, ov, ob, _, orep = oracle.nav_lm_optimize(P, N, seq["poses_init"], np.zeros((16, 3)), np.zeros(6), seq["points_init"])
+    got = np.stack([results.atPose3(X(i)).flat12() for i in range(16)])
+    assert relerr(got, op) < 1e-5                                                     # north_star: 1e-4
+    assert np.abs(np.stack([results.atVector(V(i)) for i in range(16)]) - ov).max() < 1e-5
+    assert np.abs(results.atConstantBias(B(0)).vector() - ob).max() < 1e-5
+    assert opt.iterations() == orep["iterations"] and np.isclose(opt.error(), orep["final_error"], rtol=1e-6)
+    assert orep["final_error"] < 1e-2 * orep["initial_error"]

@@ -38,21 +38,37 @@ def gather_tracks(stereo_idx: torch.Tensor, track_idx: torch.Tensor, kp_keys_lef
                   n_frames: int, world: int, rank: int):
     """all_gather of the per-frame feature-track records (BASELINE.json configs[3]).  Inputs are this
     rank's owned rows: stereo_idx [n_owned, K], track_idx [n_owned, K] (row of the last frame of the
-    stream is all -1), kp_keys_left [n_owned, K].  Returns the three full [n_frames, K] tensors."""
+    stream is all -1), kp_keys_left [n_owned, K].  Returns the three full [n_frames, K] tensors.
+    One collective: the three int32 records travel as one [3, rows, K] buffer (12 B per keypoint slot, 24 KB
+    per frame at K = 2000)."""
     K = stereo_idx.shape[1]
     counts = [shard_frames(n_frames, world, r)[1] for r in range(world)]
     mx = max(counts)
-    outs = []
-    for t in (stereo_idx, track_idx, kp_keys_left):
-        pad = torch.full((mx, K), -1, dtype=t.dtype, device=t.device)
-        pad[:t.shape[0]] = t
-        if world > 1:
-            bufs = [torch.empty_like(pad) for _ in range(world)]
-            dist.all_gather(bufs, pad)
-        else:
-            bufs = [pad]
-        outs.append(torch.cat([b[:c] for b, c in zip(bufs, counts)], 0))
-    return tuple(outs)
+    n_own = stereo_idx.shape[0]
+    assert track_idx.shape[0] == n_own and kp_keys_left.shape[0] == n_own == counts[rank]
+    pad = torch.full((3, mx, K), -1, dtype=torch.int32, device=stereo_idx.device)
+    pad[0, :n_own], pad[1, :n_own], pad[2, :n_own] = stereo_idx, track_idx, kp_keys_left.to(torch.int32)
+    if world > 1:
+        staged = pad.is_cuda and dist.get_backend() == "gloo"      # CPU rehearsal of the RCCL path
+        src = pad.cpu() if staged else pad
+        bufs = [torch.empty_like(src) for _ in range(world)]
+        dist.all_gather(bufs, src)
+        if staged:
+            bufs = [b.to(pad.device) for b in bufs]
+    else:
+        bufs = [pad]
+    return tuple(torch.cat([b[t, :c] for b, c in zip(bufs, counts)], 0) for t in range(3))
+
+
+def owned_track_records(res, n_owned: int):
+    """The rows of a FrontendResult (computed on a shard WITH its halo frame) that this rank owns, in the shape
+    gather_tracks() takes: stereo matches of the owned frames, the owned temporal pairs (the last frame of the
+    whole stream has none: a row of -1), and the left keypoint keys."""
+    K = res.stereo_idx.shape[1]
+    track = torch.full((n_owned, K), -1, dtype=torch.int32, device=res.stereo_idx.device)
+    n_pairs = min(n_owned, res.track_idx.shape[0])
+    track[:n_pairs] = res.track_idx[:n_pairs]
+    return res.stereo_idx[:n_owned], track, res.kp_keys[0:2 * n_owned:2]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -550,26 +550,158 @@ class ISAM2:
 
 # ---------------------------------------------------------------------------------------------
 # containers
+class _ValueBlock:
+    """Array-backed run of same-typed variables (EXTENSION, see Values.insert_point3_block): keys ascending,
+    data [n,3] (Point3) or [n,12] (Pose3 as row-major R then t)."""
+    __slots__ = ("kind", "keys", "data")
+
+    def __init__(self, kind, keys, data):
+        self.kind, self.keys, self.data = kind, keys, data
+
+    def find(self, keys):
+        """(position, found) of every key of the int64 array `keys` in this block."""
+        if len(self.keys) == 0:
+            return np.zeros(len(keys), np.int64), np.zeros(len(keys), bool)
+        pos = np.minimum(np.searchsorted(self.keys, keys), len(self.keys) - 1)
+        return pos, self.keys[pos] == keys
+
+
 class Values:
+    """gtsam.Values.  Variables inserted one by one (the way batch.py:274-298 does) live in a dict; the bulk
+    EXTENSION methods keep whole runs of Point3 / Pose3 variables as arrays, so that a graph with 50 000 landmarks
+    is packed for the GPU, and its result read back, without one Python object per variable."""
+
     def __init__(self, other: Optional["Values"] = None):
         self._d: Dict[int, object] = dict(other._d) if other is not None else {}
+        self._blk: List[_ValueBlock] = ([_ValueBlock(b.kind, b.keys, b.data.copy()) for b in other._blk]
+                                        if other is not None else [])
 
+    # -- block helpers ------------------------------------------------------------------------------
+    def _find_block(self, key):
+        for b in self._blk:
+            n = len(b.keys)
+            if n:
+                i = int(np.searchsorted(b.keys, key))
+                if i < n and b.keys[i] == key:
+                    return b, i
+        return None, -1
+
+    def _insert_block(self, kind, keys, data, width):
+        keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(-1)
+        data = np.array(data, dtype=float).reshape(-1, width)
+        if len(keys) != len(data):
+            raise RuntimeError("Values: keys and values differ in length")
+        order = np.argsort(keys, kind="stable")
+        keys, data = keys[order], data[order]
+        dup = len(keys) > 1 and bool((keys[1:] == keys[:-1]).any())
+        if not dup and self._d:
+            dup = any(int(k) in self._d for k in keys.tolist()) if len(keys) < len(self._d) else \
+                bool(np.isin(np.fromiter(self._d.keys(), np.int64, len(self._d)), keys).any())
+        for b in self._blk:
+            dup = dup or bool(b.find(keys)[1].any())
+        if dup:
+            raise RuntimeError("Attempting to add a key-value pair with a key which already exists in the Values.")
+        self._blk.append(_ValueBlock(kind, keys, data))
+
+    def insert_point3_block(self, keys, points):
+        """EXTENSION: vectorised `for k, p in zip(keys, points): insert(k, p)` (batch.py:297-298)."""
+        self._insert_block("point3", keys, points, 3)
+
+    def insert_pose3_block(self, keys, flat12):
+        """EXTENSION: bulk insertion of Pose3 values given as [n,12] rows (row-major R, then t)."""
+        self._insert_block("pose3", keys, flat12, 12)
+
+    insert_points = insert_point3_block
+
+    def _rows(self, kind, keys, what):
+        """[n,w] array of the variables `keys` (int64 array) of the given kind; raises like gtsam's at*()."""
+        keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(-1)
+        w = 3 if kind == "point3" else 12
+        out = np.empty((len(keys), w))
+        todo = np.ones(len(keys), bool)
+        for b in self._blk:
+            pos, hit = b.find(keys)
+            hit &= todo
+            if hit.any():
+                if b.kind != kind:
+                    k = int(keys[np.nonzero(hit)[0][0]])
+                    raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(k)}\" does not hold what {what} asks for")
+                out[hit] = b.data[pos[hit]]
+                todo &= ~hit
+        for i in np.nonzero(todo)[0].tolist():
+            k = int(keys[i])
+            if k not in self._d:
+                raise RuntimeError(f"Attempting to at the key \"{symbol_shorthand.key_string(k)}\", "
+                                   "which does not exist in the Values.")
+            v = self._d[k]
+            if kind == "pose3":
+                if not isinstance(v, Pose3):
+                    raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(k)}\" is not a Pose3")
+                out[i] = v.flat12()
+            else:
+                if not isinstance(v, np.ndarray) or v.size != 3:
+                    raise RuntimeError(f"landmark \"{symbol_shorthand.key_string(k)}\" is not a Point3")
+                out[i] = v
+        return out
+
+    def point3_block(self, keys):
+        """EXTENSION: [n,3] array of the Point3 variables `keys` (bulk atPoint3)."""
+        return self._rows("point3", keys, "atPoint3")
+
+    def pose3_block(self, keys):
+        """EXTENSION: [n,12] array (row-major R, then t) of the Pose3 variables `keys` (bulk atPose3)."""
+        return self._rows("pose3", keys, "atPose3")
+
+    def _pose3_table(self):
+        """(sorted keys, [n,12]) of every Pose3 variable."""
+        ks = [np.fromiter((k for k, v in self._d.items() if isinstance(v, Pose3)), np.int64)]
+        rows = [np.array([self._d[int(k)].flat12() for k in ks[0]]).reshape(-1, 12)]
+        for b in self._blk:
+            if b.kind == "pose3":
+                ks.append(b.keys); rows.append(b.data)
+        keys, data = np.concatenate(ks), np.concatenate(rows)
+        order = np.argsort(keys, kind="stable")
+        return keys[order], data[order]
+
+    def _store_rows(self, kind, keys, rows):
+        """Overwrite existing variables of `kind` (result write-back of the optimizer), vectorised for blocks."""
+        keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(-1)
+        todo = np.ones(len(keys), bool)
+        for b in self._blk:
+            if b.kind != kind:
+                continue
+            pos, hit = b.find(keys)
+            hit &= todo
+            b.data[pos[hit]] = rows[hit]
+            todo &= ~hit
+        for i in np.nonzero(todo)[0].tolist():
+            self._d[int(keys[i])] = Pose3.from_flat12(rows[i]) if kind == "pose3" else rows[i].copy()
+
+    # -- gtsam API ---------------------------------------------------------------------------------
     def insert(self, key, value):                                        # batch.py:274,283-288,298
         key = int(key)
-        if key in self._d:
+        if key in self._d or self._find_block(key)[0] is not None:
             raise RuntimeError(f"Attempting to add a key-value pair with key \"{symbol_shorthand.key_string(key)}\", "
                                "which already exists in the Values.")
         self._d[key] = self._coerce(value)
 
     def update(self, key, value):
         key = int(key)
+        b, i = self._find_block(key)
+        if b is not None:
+            v = self._coerce(value)
+            b.data[i] = v.flat12() if isinstance(v, Pose3) else np.asarray(v, float).reshape(-1)
+            return
         if key not in self._d:
             raise RuntimeError(f"Requested to update a key-value pair with key \"{symbol_shorthand.key_string(key)}\", "
                                "which does not exist in the Values.")
         self._d[key] = self._coerce(value)
 
     def insert_or_assign(self, key, value):
-        self._d[int(key)] = self._coerce(value)
+        if self.exists(key):
+            self.update(key, value)
+        else:
+            self.insert(key, value)
 
     @staticmethod
     def _coerce(value):
@@ -578,19 +710,29 @@ class Values:
         return np.asarray(value, dtype=float).reshape(-1).copy()
 
     def exists(self, key):                                               # batch.py:60,297
-        return int(key) in self._d
+        key = int(key)
+        return key in self._d or self._find_block(key)[0] is not None
 
     def erase(self, key):
-        if int(key) not in self._d:
-            raise RuntimeError(f"key \"{symbol_shorthand.key_string(int(key))}\" does not exist in the Values")
-        del self._d[int(key)]
+        key = int(key)
+        b, i = self._find_block(key)
+        if b is not None:
+            b.keys, b.data = np.delete(b.keys, i), np.delete(b.data, i, axis=0)
+            return
+        if key not in self._d:
+            raise RuntimeError(f"key \"{symbol_shorthand.key_string(key)}\" does not exist in the Values")
+        del self._d[key]
 
     def _at(self, key, kind, name):
         key = int(key)
-        if key not in self._d:
-            raise RuntimeError(f"Attempting to {name} the key \"{symbol_shorthand.key_string(key)}\", "
-                               "which does not exist in the Values.")
-        v = self._d[key]
+        if key in self._d:
+            v = self._d[key]
+        else:
+            b, i = self._find_block(key)
+            if b is None:
+                raise RuntimeError(f"Attempting to {name} the key \"{symbol_shorthand.key_string(key)}\", "
+                                   "which does not exist in the Values.")
+            v = Pose3.from_flat12(b.data[i]) if b.kind == "pose3" else b.data[i].copy()
         if not isinstance(v, kind):
             raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(key)}\" holds a "
                                f"{type(v).__name__}, not what {name} asks for")
@@ -612,19 +754,16 @@ class Values:
         return self._at(key, _ConstantBias, "atConstantBias")
 
     def keys(self):
-        return sorted(self._d)
+        ks = list(self._d)
+        for b in self._blk:
+            ks.extend(b.keys.tolist())
+        return sorted(ks)
 
     def size(self):
-        return len(self._d)
+        return len(self._d) + sum(len(b.keys) for b in self._blk)
 
     def __len__(self):
-        return len(self._d)
-
-    # EXTENSION: bulk insertion of landmark points (vectorised batch.py:297-298)
-    def insert_points(self, keys, points):
-        pts = np.asarray(points, dtype=float).reshape(-1, 3)
-        for k, p in zip(np.asarray(keys).reshape(-1).tolist(), pts):
-            self.insert(k, p)
+        return self.size()
 
 
 class NonlinearFactorGraph:

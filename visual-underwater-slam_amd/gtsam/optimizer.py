@@ -92,8 +92,10 @@ class _AuxPriors:
         self.x = self._cand
 
 
-def _pack_graph(graph, values):
-    """Factor graph + Values -> arrays for StereoBAProblem.  Raises on anything outside the built scope."""
+def _pack_graph(graph, values, device=None):
+    """Factor graph + Values -> arrays for StereoBAProblem.  Raises on anything outside the built scope.
+    The per-observation key -> index mapping (a sort of every landmark key) runs on `device` with torch when one
+    is given (2 M observations: ~3 ms on the GPU against ~0.3 s in numpy), else in numpy (CPU tests)."""
     from . import (GenericStereoFactor3D, StereoFactorBlock, PriorFactorPose3, PriorFactorVector, Pose3,
                    ImuFactor, CustomFactor, DvlVelocityFactor, _ConstantBias)
     meas, pkeys, lkeys = [], [], []
@@ -138,28 +140,39 @@ def _pack_graph(graph, values):
     if single_m:
         meas.append(np.asarray(single_m, dtype=float).reshape(-1, 3))
         pkeys.append(np.asarray(single_p, dtype=np.int64)); lkeys.append(np.asarray(single_l, dtype=np.int64))
-    meas = np.concatenate(meas) if meas else np.zeros((0, 3))
-    pkeys = np.concatenate(pkeys) if pkeys else np.zeros(0, np.int64)
-    lkeys = np.concatenate(lkeys) if lkeys else np.zeros(0, np.int64)
+    cat = lambda parts, empty: parts[0] if len(parts) == 1 else (np.concatenate(parts) if parts else empty)
+    meas = cat(meas, np.zeros((0, 3)))
+    pkeys = cat(pkeys, np.zeros(0, np.int64))
+    lkeys = cat(lkeys, np.zeros(0, np.int64))
 
-    pose_keys = np.array(sorted(k for k in values.keys() if isinstance(values._d[k], Pose3)), dtype=np.int64)
+    # variables: vectorised for array-backed Values blocks, per object only for individually inserted ones
+    pose_keys, poses = values._pose3_table()
     if len(pose_keys) == 0:
         raise RuntimeError("the Values hold no Pose3 variable")
-    lm_keys = np.unique(lkeys)
-    for k in np.unique(pkeys).tolist():
-        if not values.exists(k) or not isinstance(values._d[k], Pose3):
+    if device is not None:
+        import torch
+        dev = torch.device(device)
+        lk, pk = torch.from_numpy(lkeys).to(dev), torch.from_numpy(pkeys).to(dev)
+        lm_keys_t, lm_idx = torch.unique(lk, return_inverse=True)
+        pose_keys_t = torch.from_numpy(pose_keys).to(dev)
+        pose_idx = torch.searchsorted(pose_keys_t, pk)
+        hit = pose_keys_t[pose_idx.clamp(max=len(pose_keys) - 1)] == pk
+        if pk.numel() and not bool(hit.all()):
+            k = int(pk[~hit][0].item())
             raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(k)}\", which does not exist in the Values.")
-    pose_idx = np.searchsorted(pose_keys, pkeys).astype(np.int32)
-    lm_idx = np.searchsorted(lm_keys, lkeys).astype(np.int32)
-    points = np.empty((len(lm_keys), 3))
-    for j, k in enumerate(lm_keys.tolist()):
-        if not values.exists(k):
+        pose_idx, lm_idx = pose_idx.to(torch.int32), lm_idx.to(torch.int32)
+        lm_keys = lm_keys_t.cpu().numpy()
+        meas = torch.from_numpy(meas).to(dev)
+    else:
+        lm_keys, lm_idx = np.unique(lkeys, return_inverse=True)
+        upk = np.unique(pkeys)
+        at = np.minimum(np.searchsorted(pose_keys, upk), len(pose_keys) - 1)
+        if len(upk) and bool((pose_keys[at] != upk).any()):
+            k = int(upk[np.nonzero(pose_keys[at] != upk)[0][0]])
             raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(k)}\", which does not exist in the Values.")
-        v = values._d[k]
-        if not isinstance(v, np.ndarray) or v.size != 3:
-            raise RuntimeError(f"landmark \"{_sym.key_string(k)}\" is not a Point3")
-        points[j] = v
-    poses = np.stack([values._d[k].flat12() for k in pose_keys.tolist()])
+        pose_idx = np.searchsorted(pose_keys, pkeys).astype(np.int32)
+        lm_idx = lm_idx.astype(np.int32)
+    points = values.point3_block(lm_keys)
 
     pr_idx, pr_T, pr_s = [], [], []
     for f in prior_pose:
@@ -257,7 +270,8 @@ def _build_solver(pg, device="cuda:0"):
 
 def graph_error(graph, values) -> float:
     import torch
-    pg = _pack_graph(graph, values)
+    import torch as _torch
+    pg = _pack_graph(graph, values, "cuda:0" if _torch.cuda.is_available() else None)
     prob, sv = _build_solver(pg)
     dev = prob.device
     poses = torch.from_numpy(pg["poses"]).to(dev)
@@ -281,7 +295,9 @@ class LevenbergMarquardtOptimizer:
         """Runs LM to convergence and returns a NEW Values; the inputs are left untouched."""
         import torch
         from . import Values, Pose3, _ConstantBias
-        pg = _pack_graph(self._graph, self._initial)
+        from .. import _lib
+        _lib.require_gpu()                      # no CPU fallback: fail before any work is done
+        pg = _pack_graph(self._graph, self._initial, self._device)
         prob, sv = _build_solver(pg, self._device)
         aux = pg["aux"] if pg["aux"].keys else None
         nav = pg.get("nav")
@@ -303,10 +319,8 @@ class LevenbergMarquardtOptimizer:
                 out._d[k] = v.copy()
             if nav["bias_key"] is not None:
                 out._d[nav["bias_key"]] = _ConstantBias(bias[:3], bias[3:])
-        for k, T in zip(pg["pose_keys"].tolist(), poses):
-            out._d[k] = Pose3.from_flat12(T)
-        for k, p in zip(pg["lm_keys"].tolist(), points):
-            out._d[k] = p.copy()
+        out._store_rows("pose3", pg["pose_keys"], poses)
+        out._store_rows("point3", pg["lm_keys"], points)
         if aux is not None:
             for k, x in zip(aux.keys, aux.x):
                 out._d[k] = x.copy()
