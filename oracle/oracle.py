@@ -16,16 +16,43 @@ LIB_PATH = os.path.join(_HERE, "libvus_oracle.so")
 _lib = None
 
 
-def build():
-    subprocess.check_call(["make", "-C", _HERE, "-s"])
+_native = None
 
 
-def lib():
-    global _lib
+def build(target="all", *make_vars):
+    subprocess.check_call(["make", "-C", _HERE, "-s", target, *make_vars])
+
+
+def _cpu_tag():
+    """Short hash of this machine's CPU model and ISA flags: a -march=native library is only valid where it was built."""
+    import hashlib
+    txt = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith(("model name", "flags")):
+                txt += line
+                if line.startswith("flags"):
+                    break
+    except OSError:
+        pass
+    return hashlib.sha1(txt.encode()).hexdigest()[:10]
+
+
+def lib(native=False):
+    """The checker library; native=True: the -O3 -march=native build made ON this machine for timing only
+    (bench.py's cpu_baseline leg).  VUS_ORACLE_LIB overrides the checker's path (sanitizer build)."""
+    global _lib, _native
+    if native:
+        if _native is None:
+            name = f"libvus_oracle_native_{_cpu_tag()}.so"
+            build("native", f"NATIVE_LIB={name}")
+            _native = ctypes.CDLL(os.path.join(_HERE, name))
+        return _native
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        path = os.environ.get("VUS_ORACLE_LIB", LIB_PATH)
+        if not os.path.exists(path):
             build()
-        _lib = ctypes.CDLL(LIB_PATH)
+        _lib = ctypes.CDLL(path)
     return _lib
 
 

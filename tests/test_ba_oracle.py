@@ -215,3 +215,45 @@ def test_pack_and_structure_invariants():
         assert (point_of_slot[pa[sl]] == point_of_slot[pb[sl]]).all()
     with pytest.raises(NotImplementedError):
         ba_pack.pack_observations(torch.tensor([0, 0]), torch.tensor([1, 1]), torch.zeros(2, 3, dtype=torch.float64), 2, 2)
+
+
+def test_multithreaded_cpu_port_equals_the_scalar_oracle(oracle):
+    """oracle/ba_port.py + vus_oracle_ba_mt.c (the cpu_baseline "port": OpenMP kernels + LAPACK banded Cholesky)
+    walks the same LM trajectory to the same optimum as the scalar oracle; stage outputs agree to round-off."""
+    import torch
+    from oracle import ba_port
+    from visual_underwater_slam_amd import synth, ba_pack
+    s = synth.ba_sequence(40, 400, 80)
+    nL = len(s["points_gt"])
+    pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"]), torch.from_numpy(s["obs_point"]),
+                                   torch.from_numpy(s["meas"]), 40, nL)
+    st = ba_pack.build_structure(pk)
+    P = oracle.BAProblem(pk, s["K"], s["sigma"], (np.array([0], np.int32), s["poses_gt"][:1], s["prior_sigmas"][None]))
+    with ba_port.set_threads(4):
+        port = ba_port.BAPort(P, st)
+        e = port.linearize(s["poses_init"], s["points_init"])
+        lin = oracle.ba_linearize(P, s["poses_init"], s["points_init"])
+        assert np.isclose(e, lin["err"], rtol=1e-12)
+        for name in ("W", "V", "gl", "Hpp", "gp"):
+            assert np.allclose(getattr(port, name), lin[name], rtol=1e-11, atol=1e-9 * np.abs(lin[name]).max()), name
+        port.schur(0.37)
+        sch = oracle.ba_schur(P, st["band"], 0.37, lin)
+        assert np.allclose(port.gs, sch["gs"], rtol=1e-10, atol=1e-10 * np.abs(sch["gs"]).max())
+        n = 6 * 40                                       # LAPACK lower band  <->  block band
+        dense = np.zeros((n, n))
+        for d in range(port.ab.shape[0]):
+            dense[np.arange(d, n), np.arange(0, n - d)] = port.ab[d, :n - d]
+        ref = np.zeros((n, n))
+        for i in range(40):
+            for sft in range(min(i, st["band"]) + 1):
+                ref[6 * i:6 * i + 6, 6 * (i - sft):6 * (i - sft) + 6] = sch["Sband"][i, sft].reshape(6, 6)
+        ref = np.tril(ref)
+        assert np.abs(dense - ref).max() < 1e-10 * np.abs(ref).max()
+        dp, ok = port.band_solve()
+        odp, status, _ = oracle.ba_band_solve(sch["Sband"], sch["gs"])
+        assert ok and status == 0 and np.allclose(dp, odp, rtol=1e-7, atol=1e-9 * np.abs(odp).max())
+        poses, points, rep = ba_port.BAPort(P, st).optimize(s["poses_init"], s["points_init"])
+    oposes, opoints, orep = oracle.ba_lm_optimize(P, st["band"], s["poses_init"], s["points_init"])
+    assert (rep["iterations"], rep["outer"], rep["tries"], rep["status"]) == (orep["iterations"], orep["outer"], orep["tries"], orep["status"])
+    assert np.allclose(rep["err_hist"], orep["err_hist"], rtol=1e-8)
+    assert np.abs(poses - oposes).max() < 1e-7 and np.abs(points - opoints).max() < 1e-6
