@@ -3,18 +3,23 @@
 
 Primary line (BASELINE.json configs[1]): ORB detect+match stereo frames/s on a synthetic
 1280x720 stereo stream, 2000 keypoints per image, 1000 frames resident in HBM per GPU.
-One "step" = one pass of the whole front-end (FAST+NMS+smoothing, top-2000 selection, orientation
-+ rBRIEF, left->right and left(t)->left(t+1) brute-force Hamming) over the rank's 1000-frame shard.
-With N ranks every rank owns its own 1000-frame shard (frames are independent: no data-path
-collective), so the job is N*1000 frames per step: "scaling": "weak".
+One "step" = one call of StereoOrbFrontend.process() -- the product's own call sequence: FAST+NMS+smoothing,
+top-2000 selection, orientation + rBRIEF, left->right and left(t)->left(t+1) brute-force Hamming -- over the rank's
+shard of the stream, timed per stage with HIP events recorded through the front-end's stage hook.
+With N ranks (BASELINE.json configs[3]) the stream has N*1000 frames, every rank owns a contiguous 1000-frame
+shard plus a one-frame halo (dist.shard_frames), and the step ends with the all_gather of the per-frame feature-track
+records (dist.gather_tracks, RCCL): "scaling": "weak".
 
-The same JSON line carries `roofline` (dominant kernel, HIP-event timed inside the timed region),
-`cpu_baseline` (the C oracle on a bounded sample of the same stream, on this host's cores) and,
-once the BA kernels exist, `ba` (full-batch LM wall time at 2000 keyframes / 50k landmarks).
+The same JSON line carries `roofline` (dominant kernel: HBM reading + the VALU-issue reading that actually binds
+it), `cpu_baseline` (OpenCV if this machine has it, else the C port, on a bounded sample of the same stream, 1 thread
+and all usable cores) and `ba`: the second half of the metric, full-batch LM wall time at 2000 keyframes / 50k
+landmarks (configs[2]) with its own roofline, drop-in boundary timing and CPU baseline; with N > 1 ranks `ba_sharded`:
+the landmark-sharded LM of configs[4].
 """
 import argparse
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -27,6 +32,7 @@ import torch  # noqa: E402
 H, W, KP = 720, 1280, 2000
 INT8_PEAK_TOPS = 5000.0   # dense int8 MFMA: 2x the ~2.5 PFLOP/s dense bf16 peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+N_SIMD = 256 * 4       # 256 CUs x 4 SIMDs
 
 # Algorithmic bytes (single pyramid level), per stereo frame:
 #   fast_detect : 2 images read once (2*H*W) + 2*2000 keypoint records of 16 B
@@ -41,6 +47,7 @@ ALGO_BYTES = {
     "hamming_track": 2 * KP * 32 + KP * 8,
 }
 ALGO_BYTES_FRAME = 2 * H * W + 2 * KP * 16 + 2 * KP * 32 + 2 * KP * 32 + KP * 8  # = 2,179,200
+STAGES = ["fast_detect", "select_topk", "orient_rbrief", "hamming_stereo", "hamming_track"]
 
 
 def parse():
@@ -49,14 +56,34 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--frames", type=int, default=1000, help="frames per GPU (configs[1]: 1000)")
-    ap.add_argument("--cpu-frames", type=int, default=64, help="bounded cpu_baseline sample")
+    ap.add_argument("--cpu-frames", type=int, default=0, help="bounded cpu_baseline sample (0: sized from the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--ba-sharded-kf", type=int, default=10000, help="keyframes of the configs[4] leg run with N > 1 ranks")
     ap.add_argument("--pyramid", action="store_true", help="also measure the same stream through the 8-level x1.2 pyramid "
                     "(extra `pyramid8` object; off by default so that a profile of the default command sees one launch "
                     "shape per kernel)")
     ap.add_argument("--no-pyramid", action="store_true", help="accepted for older scripts; the default already")
     return ap.parse_args()
+
+
+def usable_cores():
+    """Cores this process may really use: the affinity mask capped by the cgroup CPU quota (a GPU box hands a
+    one-GPU job a share of the host, not all of it)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(p))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return n
 
 
 def make_stream(n_frames, t0, device):
@@ -70,103 +97,148 @@ def make_stream(n_frames, t0, device):
     return out
 
 
-def timed_stage_process(fe, images, events):
-    """fe.process() with a HIP event recorded (on the launch stream) around every kernel."""
-    from visual_underwater_slam_amd import _lib
-    p, F, K = fe.p, images.shape[0], fe.p.max_features
-    n_img = 2 * F
-    st = _lib.current_stream_ptr()
-    ptr = _lib.ptr
-    fe.cand_count[:n_img].zero_()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
-    ev[0].record()
-    _lib.call("vus_fast_detect", ptr(images), n_img, H, W, W, p.fast_threshold, p.border, ptr(fe.blur),
-              ptr(fe.cand_keys), p.cand_cap, ptr(fe.cand_count), st)
-    ev[1].record()
-    _lib.call("vus_select_topk", ptr(fe.cand_keys), ptr(fe.cand_count), n_img, p.cand_cap, K,
-              ptr(fe.kp_keys), ptr(fe.kp_count), st)
-    ev[2].record()
-    _lib.call("vus_orient_rbrief", ptr(images), ptr(fe.blur), n_img, H, W, W, ptr(fe.kp_keys),
-              ptr(fe.kp_count), K, ptr(fe.desc), ptr(fe.angle), st)
-    ev[3].record()
-    _lib.call("vus_hamming_match", ptr(fe.desc), ptr(fe.kp_keys), ptr(fe.kp_count), K, H, W, ptr(fe.stereo_q),
-              ptr(fe.stereo_t), F, p.stereo_threshold, p.min_disparity, p.max_disparity,
-              p.stereo_max_distance, ptr(fe.match_idx), ptr(fe.match_dist), st)
-    ev[4].record()
-    _lib.call("vus_hamming_match", ptr(fe.desc), ptr(fe.kp_keys), ptr(fe.kp_count), K, H, W, ptr(fe.track_q),
-              ptr(fe.track_t), F - 1, -1, 0, 0, p.track_max_distance, ptr(fe.match_idx[fe.max_frames:]),
-              ptr(fe.match_dist[fe.max_frames:]), st)
-    ev[5].record()
-    events.append(ev)
+class StageTimer:
+    """HIP events on the launch stream, recorded through StereoOrbFrontend.stage_hook (torch's current stream is the
+    stream the C ABI launches on)."""
+
+    def __init__(self):
+        self.steps = []
+
+    def __call__(self, name):
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        if name == "begin":
+            self.steps.append([])
+        self.steps[-1].append((name, ev))
+
+    def stage_ms(self):
+        acc = {}
+        for st in self.steps:
+            for (_, e0), (n1, e1) in zip(st, st[1:]):
+                acc.setdefault(n1, []).append(e0.elapsed_time(e1))
+        return {k: sum(v) / len(v) for k, v in acc.items() if k != "end"}
 
 
-def measured_traffic(kernel, frames):
-    """HBM bytes per launch of `kernel` from the committed PMC summary (profiles/traffic.json: bytes per
-    image measured by tools/collect_profiles.sh with rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-    passes).  Returns None when the file is absent."""
+def measured_counters(kernel, frames):
+    """Per-launch HBM bytes and VALU wave-instructions of `kernel` from the committed PMC summary
+    (profiles/traffic.json: per-image figures measured by tools/collect_profiles.sh with rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE / SQ_INSTS_VALU in separate passes).  (None, None) when the file is absent."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
-    if not os.path.exists(path):
-        return None
     try:
         t = json.load(open(path))
         key = {"fast_detect": "fast_tile_kernel", "orient_rbrief": "orient_rbrief_kernel",
                "select_topk": "select_topk_kernel", "hamming_stereo": "hamming_match_rows_kernel",
-               "hamming_track": "hamming_match_kernel"}[kernel]
+               "hamming_track": "hamming_match_mfma_kernel"}[kernel]
         per_img = t["bytes_per_image"][key]
-        return int((per_img["fetch"] + per_img["write"]) * 2 * frames)
+        traffic = int((per_img["fetch"] + per_img["write"]) * 2 * frames)
+        valu = t.get("valu_wave_insts_per_image", {}).get(key)
+        return traffic, (None if valu is None else valu * 2 * frames), t.get("valu_ns_per_wave_inst_per_simd", {}).get(key)
     except Exception:
-        return None
+        return None, None, None
 
 
-def cpu_baseline(n_frames, t0):
-    """The C oracle ("port") on the first n_frames of the same stream, all host cores."""
+def cpu_baseline_frontend(t0, cores, requested_frames):
+    """M1 on the host CPU.  OpenCV (the engine the reference's nodelet runs) if this machine has it, else the C port
+    (-O3 -march=native build made here, OpenMP over images).  1 thread and all usable cores, median of 5 after a
+    warm-up; the sample is sized so that every thread has an image to work on."""
     import numpy as np
     from visual_underwater_slam_amd import synth
-    from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    O.lib().vus_oracle_set_threads(cores)
-    img = synth.stereo_frames(t0, n_frames).reshape(2 * n_frames, H, W)
-    t = time.perf_counter()
-    keys, cnt, blur = O.fast_detect(img)
-    kp, kc = O.select_topk(keys, cnt, KP)
-    desc, _ = O.orient_rbrief(img, blur, kp, kc)
-    f = np.arange(n_frames, dtype=np.int32)
-    O.hamming_match(desc, kp, kc, W, 2 * f, 2 * f + 1, 5, 0, 128, 64)
-    O.hamming_match(desc, kp, kc, W, 2 * f[:-1], 2 * f[:-1] + 2, -1, 0, 0, 64)
-    dt = time.perf_counter() - t
-    return {"value": round(n_frames / dt, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "sample": f"first {n_frames} stereo frames of the same synthetic stream, C oracle "
-                      f"(gcc -O2, OpenMP over images), {dt:.2f} s"}
+    from oracle import oracle as O, engines
+    probe = engines.probe()
+    out = {"engines": engines.describe(probe)}
+    n_all = requested_frames or max(16, min(64, cores))           # 2 images per frame: >= 2 per thread up to 64 cores
+    img_all = synth.stereo_frames(t0, n_all)
+    if probe["cv2"] is not None:
+        try:
+            import cv2
+            def run_cv(n):
+                t = time.perf_counter()
+                for f in range(n):
+                    engines.cv2_orb_detect_match(img_all[f, 0], img_all[f, 1], KP, 10)
+                return time.perf_counter() - t
+            cv2.setNumThreads(cores)
+            run_cv(1)
+            ts = [run_cv(min(n_all, 8)) for _ in range(5)]
+            dt = statistics.median(ts)
+            out.update({"value": round(min(n_all, 8) / dt, 3), "unit": "frames/s", "cores": cores, "kind": "reference",
+                        "sample": f"cv2 {probe['cv2']} ORB_create(nfeatures=2000, fastThreshold=10) + BFMatcher(NORM_HAMMING) "
+                                  f"left->right on the first {min(n_all, 8)} stereo frames, median of 5, cv2.setNumThreads({cores})"})
+            return out
+        except Exception as e:
+            out["cv2_error"] = str(e)
+    lib = O.lib(native=True)
+
+    def run(n, threads):
+        lib.vus_oracle_set_threads(threads)
+        img = img_all[:n].reshape(2 * n, H, W)
+        t = time.perf_counter()
+        keys, cnt, blur = O.fast_detect(img, _lib=lib)
+        kp, kc = O.select_topk(keys, cnt, KP, _lib=lib)
+        desc, _ = O.orient_rbrief(img, blur, kp, kc, _lib=lib)
+        f = np.arange(n, dtype=np.int32)
+        O.hamming_match(desc, kp, kc, W, 2 * f, 2 * f + 1, 5, 0, 128, 64, _lib=lib)
+        if n > 1:
+            O.hamming_match(desc, kp, kc, W, 2 * f[:-1], 2 * f[:-1] + 2, -1, 0, 0, 64, _lib=lib)
+        return time.perf_counter() - t
+    run(min(n_all, 4), cores)                                       # warm-up
+    t_all = statistics.median(run(n_all, cores) for _ in range(5))
+    n_one = 2
+    t_one = statistics.median(run(n_one, 1) for _ in range(3))
+    out.update({"value": round(n_all / t_all, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+                "value_1thread": round(n_one / t_one, 3),
+                "sample": f"C port (gcc -O3 -march=native, OpenMP over the {2 * n_all} images): first {n_all} stereo frames of "
+                          f"the same stream, {cores} threads, median of 5 = {t_all:.2f} s; 1 thread: first {n_one} frames, "
+                          f"median of 3 = {t_one:.2f} s.  Not OpenCV: cv2 is absent on this machine"})
+    return out
 
 
-def ba_cpu_baseline(device):
-    """The C oracle's LM (single thread, "port") against the GPU solver on a bounded BA problem
-    (400 keyframes / 10k landmarks / 400 observations per keyframe): the full configs[2] problem would
-    keep one CPU core busy for minutes."""
+def cpu_baseline_ba(seq, cores, gpu_seconds):
+    """M2 on the host CPU at the SAME configs[2] problem.  gtsam (the engine batch.py:337 calls) if present, else the
+    CPU port: OpenMP kernels (-O3 -march=native) + LAPACK banded Cholesky (oracle/ba_port.py)."""
     import numpy as np
-    from visual_underwater_slam_amd import synth, ba_pack
-    from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
-    from oracle import oracle as O
-    n_kf, n_lm, obs = 400, 10000, 400
-    s = synth.ba_sequence(n_kf, n_lm, obs)
-    nL = len(s["points_gt"])
-    pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"]), torch.from_numpy(s["obs_point"]),
-                                   torch.from_numpy(s["meas"]), n_kf, nL)
+    from visual_underwater_slam_amd import ba_pack
+    from oracle import oracle as O, engines, ba_port
+    probe = engines.probe()
+    out = {"engines": engines.describe(probe)}
+    n_kf, nL = len(seq["poses_init"]), len(seq["points_gt"])
+    if probe["gtsam"] is not None:
+        try:
+            t = time.perf_counter()
+            _, _, err, its = engines.gtsam_stereo_lm(seq, prior_on_gt=True)
+            dt = time.perf_counter() - t
+            out.update({"value": round(dt, 3), "unit": "s", "cores": cores, "kind": "reference",
+                        "sample": f"gtsam {probe['gtsam']} LevenbergMarquardtOptimizer default params on the same graph "
+                                  f"(includes the per-factor graph build), {its} iterations, final error {err:.1f}; one run",
+                        "gpu_speedup": round(dt / gpu_seconds, 1)})
+            return out
+        except Exception as e:
+            out["gtsam_error"] = str(e)
+    pk = ba_pack.pack_observations(torch.from_numpy(seq["obs_pose"]), torch.from_numpy(seq["obs_point"]),
+                                   torch.from_numpy(seq["meas"]), n_kf, nL)
     st = ba_pack.build_structure(pk)
-    P = O.BAProblem(pk, s["K"], s["sigma"], (np.array([0], np.int32), s["poses_gt"][:1], s["prior_sigmas"][None]))
-    t = time.perf_counter()
-    _, _, rep = O.ba_lm_optimize(P, st["band"], s["poses_init"], s["points_init"])
-    cpu_s = time.perf_counter() - t
-    prob = StereoBAProblem(s["obs_pose"], s["obs_point"], s["meas"], n_kf, nL, s["K"], s["sigma"], prior_pose=[0],
-                           prior_T=s["poses_gt"][:1], prior_sigmas=s["prior_sigmas"][None], device=device)
-    sv = StereoBASolver(prob)
-    p0, x0 = torch.from_numpy(s["poses_init"]).to(device), torch.from_numpy(s["points_init"]).to(device)
-    sv.optimize(p0, x0)
-    _, _, grep = sv.optimize(p0, x0)
-    return {"value": round(cpu_s, 3), "unit": "s", "cores": 1, "kind": "port",
-            "sample": f"full LM on {n_kf} keyframes / {nL} landmarks / {prob.n_obs} stereo factors (band {prob.band}), "
-                      f"C oracle gcc -O2, {rep['tries']} linear solves",
-            "gpu_same_problem_s": round(grep.seconds, 4), "gpu_speedup": round(cpu_s / grep.seconds, 1)}
+    P = O.BAProblem(pk, seq["K"], seq["sigma"], (np.array([0], np.int32), seq["poses_gt"][:1], seq["prior_sigmas"][None]))
+    runs = []
+    with ba_port.set_threads(cores):
+        for _ in range(3):
+            _, _, rep = ba_port.BAPort(P, st, native=True).optimize(seq["poses_init"], seq["points_init"], max_seconds=60)
+            runs.append(rep)
+    rep = sorted(runs, key=lambda r: r["seconds"])[1]
+    with ba_port.set_threads(1):
+        _, _, rep1 = ba_port.BAPort(P, st, native=True).optimize(seq["poses_init"], seq["points_init"], max_seconds=30)
+    out.update({
+        "value": round(rep["seconds"], 3), "unit": "s", "cores": cores, "kind": "port",
+        "sample": f"full LM at configs[2] ({n_kf} keyframes / {nL} landmarks / {len(seq['obs_pose'])} stereo factors): CPU port = "
+                  f"OpenMP kernels (gcc -O3 -march=native) + LAPACK dpbtrf/dpbtrs (scipy OpenBLAS), {cores} threads, median of 3, "
+                  f"{rep['tries']} linear solves" + (" (stopped at the 60 s bound)" if rep["truncated"] else "") +
+                  ".  Not GTSAM: gtsam is absent on this machine",
+        "s_per_linear_solve": round(rep["seconds"] / max(rep["tries"], 1), 3),
+        "stage_s": {k: round(v, 3) for k, v in rep["stage_s"].items()},
+        "final_error": rep["final_error"],
+        "one_thread": {"seconds": round(rep1["seconds"], 3), "linear_solves": rep1["tries"], "truncated_at_30s": rep1["truncated"],
+                       "s_per_linear_solve": round(rep1["seconds"] / max(rep1["tries"], 1), 3)},
+        "gpu_speedup": round(rep["seconds"] / gpu_seconds, 1) if not rep["truncated"] else None,
+    })
+    return out
 
 
 def main():
@@ -179,8 +251,8 @@ def main():
     dev_index = local % max(torch.cuda.device_count(), 1) if backend != "nccl" else local
     device = torch.device("cuda", dev_index)
     torch.cuda.set_device(device)
+    import torch.distributed as dist
     if world > 1:
-        import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=device)
@@ -188,42 +260,54 @@ def main():
             dist.init_process_group(backend)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
 
+    from visual_underwater_slam_amd import dist as vdist
     from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
     F = a.frames
-    images = make_stream(F, rank * F, device)        # this rank's shard of the stream, resident in HBM
-    fe = StereoOrbFrontend(H, W, max_frames=F, params=ImageProcessorParams(max_features=KP), device=device)
+    n_stream = world * F
+    first, n_owned, n_halo = vdist.shard_frames(n_stream, world, rank)     # weak scaling: F owned frames per rank
+    images = make_stream(n_halo, first, device)      # this rank's shard (+ halo frame) of the stream, resident in HBM
+    fe = StereoOrbFrontend(H, W, max_frames=n_halo, params=ImageProcessorParams(max_features=KP), device=device)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
+    def step():
+        res = fe.process(images, check=False)
+        if world > 1:          # configs[3]: the step ends with the gather of the stream's feature-track records
+            vdist.gather_tracks(*vdist.owned_track_records(res, n_owned), n_stream, world, rank)
+
     # set-up pass (not a step): loads the code objects, validates that no image overflowed the candidate
     # buffer, and lets the clocks settle -- the first ~10 launches after an idle period run ~10 % slow
     for _ in range(8):
-        fe.process(images, check=False)
+        step()
     barrier()
     fe.check_overflow()
     for _ in range(a.warmup):
-        fe.process(images, check=False)
+        step()
     barrier()
-    events = []
+    timer = StageTimer()
+    fe.stage_hook = timer
     barrier()
     t0 = time.perf_counter()
     for _ in range(a.steps):
-        timed_stage_process(fe, images, events)
+        step()
     barrier()
     dt = time.perf_counter() - t0
+    fe.stage_hook = None
+    fe.check_overflow()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
-    names = ["fast_detect", "select_topk", "orient_rbrief", "hamming_stereo", "hamming_track"]
-    stage_ms = {n: sum(ev[i].elapsed_time(ev[i + 1]) for ev in events) / len(events) for i, n in enumerate(names)}
+    stage_ms = timer.stage_ms()
+    stage_ms = {n: stage_ms[n] for n in STAGES}
     dom = max(stage_ms, key=stage_ms.get)
-    achieved = ALGO_BYTES[dom] * F / (stage_ms[dom] * 1e-3) / 1e9
-    traffic = measured_traffic(dom, F)
+    n_proc = n_halo                                          # frames this rank's launches really covered
+    achieved = ALGO_BYTES[dom] * n_proc / (stage_ms[dom] * 1e-3) / 1e9
+    traffic, valu_insts, valu_ns = measured_counters(dom, n_proc)
     out = {
         "metric": "ORB detect+match frames/sec", "value": round(world * F * a.steps / dt, 2),
         "unit": "stereo frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -232,57 +316,82 @@ def main():
         "config": {"workload": "configs[1]: stereo ORB detect+match, 1280x720, 2000 kpts/image, "
                                f"{F}-frame stream per GPU resident in HBM, single pyramid level",
                    "frames_per_gpu": F, "keypoints_per_image": KP, "fast_threshold": 10,
-                   "parallelism": f"frames sharded x{world}, no data-path collective"},
+                   "parallelism": (f"frames sharded x{world} (+1 halo frame per shard), all_gather of the feature-track "
+                                   f"records inside the step" if world > 1 else "1 GPU, no collective")},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "pipeline_GBps": round(ALGO_BYTES_FRAME * F * a.steps / dt / 1e9 * world, 2),
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
-                     "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * F,
-                     "note": "fast_detect is VALU-issue bound (integer min/max/SDWA ops issue at 0.57x the fp32 "
-                             "rate, profiles/valu_issue_rates_*.txt); traffic = FETCH_SIZE+WRITE_SIZE of a separate "
-                             "rocprofv3 --pmc run (profiles/traffic.json), scaled to this launch"},
+                     "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * n_proc,
+                     "note": "HBM reading of a kernel that is VALU-issue bound (see `valu`): traffic = FETCH_SIZE+WRITE_SIZE of "
+                             "a separate rocprofv3 --pmc run (profiles/traffic.json), scaled to this launch"},
     }
+    if valu_insts and valu_ns:
+        # the roof that binds: VALU wave-instructions of the launch x the measured issue cost of this instruction mix
+        # (ns per wave-instruction per SIMD, tools/ubench/valu_rate.hip) spread over the chip's SIMDs = the time the
+        # vector ALUs need even with every byte already on chip
+        t_valu_ms = valu_insts * valu_ns * 1e-9 / N_SIMD * 1e3
+        out["roofline"]["valu"] = {
+            "bound": "valu-issue", "wave_insts_per_launch": int(valu_insts), "ns_per_wave_inst_per_simd": valu_ns,
+            "simds": N_SIMD, "floor_ms": round(t_valu_ms, 3), "measured_ms": round(stage_ms[dom], 3),
+            "frac": round(t_valu_ms / stage_ms[dom], 3),
+            "note": "SQ_INSTS_VALU (PMC) x issue cost of the integer min/max/byte-select mix (0.57x the fp32 rate on gfx950) "
+                    "/ 1024 SIMDs: the kernel runs at this fraction of its own instruction-issue floor"}
     # second bound, informational: the track matcher is an int8 GEMM on the matrix cores (2000 x 2000 x 256 multiply-
     # accumulates per image pair = the algorithmic work of brute-force Hamming matching in its dot-product form)
-    mm_ops = 2.0 * (F - 1) * KP * KP * 256
+    mm_ops = 2.0 * (n_proc - 1) * KP * KP * 256
     out["roofline_matcher"] = {"kernel": "hamming_track", "bound": "mfma", "achieved": round(mm_ops / (stage_ms["hamming_track"] * 1e-3) / 1e12, 1),
                                "peak": INT8_PEAK_TOPS, "unit": "TOP/s", "frac": round(mm_ops / (stage_ms["hamming_track"] * 1e-3) / 1e12 / INT8_PEAK_TOPS, 4),
                                "note": "dense int8 MFMA peak = 2x the ~2.5 PFLOP/s bf16 peak (MI355X_MICROARCH.md, matrix cores)"}
+    if world > 1:
+        out["stage_ms"]["gather_tracks_and_rest"] = round(dt / a.steps * 1e3 - sum(stage_ms.values()), 4)
+    cores = usable_cores()
+    if rank == 0 and not a.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline_frontend(0, cores, a.cpu_frames)
+    if rank == 0 and a.pyramid and not a.no_pyramid and world == 1:
+        # extra figure, not the headline: the same stream through the 8-level x1.2 ORB pyramid
+        # (2,853,088 px per image, per-level quotas summing to 2000 keypoints)
+        del fe
+        torch.cuda.empty_cache()
+        fp = StereoOrbFrontend(H, W, max_frames=F, device=device,
+                               params=ImageProcessorParams(max_features=KP, n_levels=8, scale_factor=1.2))
+        fp.process(images, check=True)
+        torch.cuda.synchronize()
+        tp = time.perf_counter()
+        for _ in range(a.steps):
+            fp.process(images, check=False)
+        torch.cuda.synchronize()
+        dtp = (time.perf_counter() - tp) / a.steps
+        out["pyramid8"] = {"value": round(F / dtp, 2), "unit": "stereo frames/s", "ms_per_step": round(dtp * 1e3, 4),
+                           "config": "8 levels x1.2 (1280x720 ... 357x201), detector/top-K/descriptor per level, "
+                                     "level-major merge to 2000 keypoints per image, same matchers",
+                           "algorithmic_GBps": round(17224352 * F / dtp / 1e9, 2)}
+        del fp
+    fe = None
+    del images
+    torch.cuda.empty_cache()
+    if not a.no_ba and world == 1:
+        from visual_underwater_slam_amd import ba_bench
+        ba = ba_bench.run(device)
+        seq = ba.pop("_seq")
+        # the reference's complete graph (stereo + IMU + DVL + priors) at its own plumbing size, configs[0] ...
+        ba["full_graph_configs0"] = ba_bench.run_full_graph(device, 50, 500, 100)
+        # ... and at 2000 keyframes: the sparse track of round 1 (about 120 factors per keyframe) and a dense one at the
+        # configs[2] factor count (2000 keyframes / ~50k landmarks / 2.0 M stereo factors + 1999 IMU + 1999 DVL)
+        ba["full_graph_2000kf_sparse"] = ba_bench.run_full_graph(device, 2000, 50000, 1000)
+        ba["full_graph_2000kf_2Mfactors"] = ba_bench.run_full_graph(device, 2000, 180000, 1000, kf_period=0.04)
+        if not a.no_cpu_baseline:
+            ba["cpu_baseline"] = cpu_baseline_ba(seq, cores, ba["value"])
+        out["ba"] = ba
+    if not a.no_ba and world > 1:
+        from visual_underwater_slam_amd import ba_bench
+        r = ba_bench.run_sharded(device, world, rank, n_kf=a.ba_sharded_kf, n_lm=50 * a.ba_sharded_kf)
+        t = torch.tensor([r["seconds"]], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        r["value"], r["unit"], r["metric"] = round(float(t.item()), 4), "s", "landmark-sharded full-batch LM wall time (max over ranks)"
+        r.pop("seconds")
+        out["ba_sharded"] = r
     if rank == 0:
-        if not a.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(a.cpu_frames, 0)
-        if a.pyramid and not a.no_pyramid and world == 1:
-            # extra figure, not the headline: the same stream through the 8-level x1.2 ORB pyramid
-            # (2,853,088 px per image, per-level quotas summing to 2000 keypoints)
-            del fe
-            torch.cuda.empty_cache()
-            fp = StereoOrbFrontend(H, W, max_frames=F, device=device,
-                                   params=ImageProcessorParams(max_features=KP, n_levels=8, scale_factor=1.2))
-            fp.process(images, check=True)
-            torch.cuda.synchronize()
-            tp = time.perf_counter()
-            for _ in range(a.steps):
-                fp.process(images, check=False)
-            torch.cuda.synchronize()
-            dtp = (time.perf_counter() - tp) / a.steps
-            out["pyramid8"] = {"value": round(F / dtp, 2), "unit": "stereo frames/s", "ms_per_step": round(dtp * 1e3, 4),
-                               "config": "8 levels x1.2 (1280x720 ... 357x201), detector/top-K/descriptor per level, "
-                                         "level-major merge to 2000 keypoints per image, same matchers",
-                               "algorithmic_GBps": round(17224352 * F / dtp / 1e9, 2)}
-            del fp
-            fe = None
-        if not a.no_ba and world == 1:
-            from visual_underwater_slam_amd import ba_bench
-            del images
-            fe = None
-            torch.cuda.empty_cache()
-            out["ba"] = ba_bench.run(device)
-            # the reference's complete graph (stereo + IMU + DVL + priors) at its own plumbing size, configs[0]
-            out["ba"]["full_graph_configs0"] = ba_bench.run_full_graph(device, 50, 500, 100)
-            # ... and the same complete graph at the configs[2] keyframe count
-            out["ba"]["full_graph_configs2"] = ba_bench.run_full_graph(device, 2000, 50000, 1000)
-            if not a.no_cpu_baseline:
-                out["ba"]["cpu_baseline"] = ba_cpu_baseline(device)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -86,23 +86,23 @@ def blur7(img):
     return out
 
 
-def fast_detect(img, thr=10, border=31, cand_cap=32768, want_blur=True):
+def fast_detect(img, thr=10, border=31, cand_cap=32768, want_blur=True, _lib=None):
     img, n, H, W = _img_args(img)
     keys = np.full((n, cand_cap), 0xFFFFFFFF, np.uint32)
     cnt = np.zeros(n, np.int32)
     blur = np.empty((n, H, W), np.uint8) if want_blur else None
-    _check(lib().vus_fast_detect_cpu(_p(img), n, H, W, W, int(thr), int(border), _p(blur), _p(keys),
+    _check((_lib or lib()).vus_fast_detect_cpu(_p(img), n, H, W, W, int(thr), int(border), _p(blur), _p(keys),
                                      int(cand_cap), _p(cnt)), "fast_detect")
     return keys, cnt, blur
 
 
-def select_topk(cand_keys, cand_count, max_kp):
+def select_topk(cand_keys, cand_count, max_kp, _lib=None):
     cand_keys = np.ascontiguousarray(cand_keys, np.uint32)
     cand_count = np.ascontiguousarray(cand_count, np.int32)
     n, cap = cand_keys.shape
     kp = np.empty((n, max_kp), np.uint32)
     cnt = np.empty(n, np.int32)
-    _check(lib().vus_select_topk_cpu(_p(cand_keys), _p(cand_count), n, cap, int(max_kp), _p(kp), _p(cnt)),
+    _check((_lib or lib()).vus_select_topk_cpu(_p(cand_keys), _p(cand_count), n, cap, int(max_kp), _p(kp), _p(cnt)),
            "select_topk")
     return kp, cnt
 
@@ -118,7 +118,7 @@ def select_grid(cand_keys, cand_count, H, W, grid_row, grid_col, per_cell, max_k
     return kp, cnt
 
 
-def orient_rbrief(img, blur, kp_keys, kp_count):
+def orient_rbrief(img, blur, kp_keys, kp_count, _lib=None):
     img, n, H, W = _img_args(img)
     blur = np.ascontiguousarray(blur, np.uint8)
     kp_keys = np.ascontiguousarray(kp_keys, np.uint32)
@@ -126,7 +126,7 @@ def orient_rbrief(img, blur, kp_keys, kp_count):
     max_kp = kp_keys.shape[1]
     desc = np.empty((n, max_kp, 4), np.uint64)
     ang = np.empty((n, max_kp), np.uint8)
-    _check(lib().vus_orient_rbrief_cpu(_p(img), _p(blur), n, H, W, W, _p(kp_keys), _p(kp_count), max_kp,
+    _check((_lib or lib()).vus_orient_rbrief_cpu(_p(img), _p(blur), n, H, W, W, _p(kp_keys), _p(kp_count), max_kp,
                                        _p(desc), _p(ang)), "orient_rbrief")
     return desc, ang
 
@@ -169,7 +169,7 @@ def new_merged(n_img, max_kp):
 
 
 def hamming_match(desc, kp_keys, kp_count, W, q_index, t_index, max_dy=-1, min_disp=0, max_disp=0,
-                  max_dist=256, H=None):
+                  max_dist=256, H=None, _lib=None):
     desc = np.ascontiguousarray(desc, np.uint64)
     kp_keys = np.ascontiguousarray(kp_keys, np.uint32)
     kp_count = np.ascontiguousarray(kp_count, np.int32)
@@ -181,7 +181,7 @@ def hamming_match(desc, kp_keys, kp_count, W, q_index, t_index, max_dy=-1, min_d
     dist = np.empty((npairs, max_kp), np.int32)
     if H is None:   # any bound on the row index will do for the oracle
         H = int((kp_keys & 0xFFFFFF).max()) // int(W) + 1 if kp_keys.size else 1
-    _check(lib().vus_hamming_match_cpu(_p(desc), _p(kp_keys), _p(kp_count), max_kp, int(H), int(W), _p(q_index),
+    _check((_lib or lib()).vus_hamming_match_cpu(_p(desc), _p(kp_keys), _p(kp_count), max_kp, int(H), int(W), _p(q_index),
                                        _p(t_index), npairs, int(max_dy), int(min_disp), int(max_disp),
                                        int(max_dist), _p(idx), _p(dist)), "hamming_match")
     return idx, dist

@@ -151,19 +151,21 @@ int vus_select_topk_cpu(const uint32_t* cand_keys, const int* cand_count, int n_
                         int max_kp, uint32_t* kp_keys, int* kp_count) {
   if (!cand_keys || !cand_count || !kp_keys || !kp_count || max_kp < 1 || cand_cap < 1)
     return VUS_E_INVALID;
-  uint32_t* tmp = (uint32_t*)malloc((size_t)cand_cap * sizeof(uint32_t));
-  if (!tmp) return VUS_E_INVALID;
+  int failed = 0;
+#pragma omp parallel for schedule(dynamic)
   for (int n = 0; n < n_img; ++n) {
     int cnt = cand_count[n] < cand_cap ? cand_count[n] : cand_cap;
+    uint32_t* tmp = (uint32_t*)malloc((size_t)(cnt > 0 ? cnt : 1) * sizeof(uint32_t));   /* per-image scratch */
+    if (!tmp) { failed = 1; continue; }
     memcpy(tmp, cand_keys + (size_t)n * cand_cap, (size_t)cnt * sizeof(uint32_t));
     qsort(tmp, (size_t)cnt, sizeof(uint32_t), cmp_u32);
     int k = cnt < max_kp ? cnt : max_kp;
     uint32_t* o = kp_keys + (size_t)n * max_kp;
     for (int i = 0; i < max_kp; ++i) o[i] = i < k ? tmp[i] : VUS_KEY_INVALID;
     kp_count[n] = k;
+    free(tmp);
   }
-  free(tmp);
-  return VUS_OK;
+  return failed ? VUS_E_INVALID : VUS_OK;
 }
 
 /* Grid-bucketed selection (include/vus.h: vus_select_grid). */

@@ -153,9 +153,19 @@ def ba_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, line_len=None, kf_step=0.25, 
                     -1.2 + (ext_y + 2.4) * _hash_uniform(j, seed ^ 0x2222),
                     2.0 + 4.0 * _hash_uniform(j, seed ^ 0x3333)], 1)
     obs_p, obs_l, meas = [], [], []
+    # Only landmarks inside the image footprint can be visible: |world dy| = |camera y| <= (RES_Y / fy) * depth.
+    # Culling by a y-window first (landmarks sorted by y once) changes nothing in the output -- the candidates
+    # keep their ascending index order -- and makes the 10 000-keyframe / 500 000-landmark sequence of
+    # configs[4] a matter of seconds instead of minutes.
+    y_order = np.argsort(pts[:, 1], kind="stable")
+    y_sorted = pts[y_order, 1]
+    y_reach = max(cy, RES_Y - cy) / fy * 6.0 + 1e-6
     for i in range(n_kf):
         R = poses[i, :9].reshape(3, 3)
-        q = (pts - poses[i, 9:]) @ R          # rows: R^T (p - t)
+        lo = np.searchsorted(y_sorted, poses[i, 10] - y_reach, "left")
+        hi = np.searchsorted(y_sorted, poses[i, 10] + y_reach, "right")
+        cand = np.sort(y_order[lo:hi])
+        q = (pts[cand] - poses[i, 9:]) @ R    # rows: R^T (p - t)
         z = q[:, 2]
         with np.errstate(divide="ignore", invalid="ignore"):
             uL = cx + fx * q[:, 0] / z
@@ -168,7 +178,7 @@ def ba_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, line_len=None, kf_step=0.25, 
             idx = idx[np.argsort(d2, kind="stable")[:obs_per_kf]]
             idx.sort()
         obs_p.append(np.full(len(idx), i, np.int32))
-        obs_l.append(idx.astype(np.int32))
+        obs_l.append(cand[idx].astype(np.int32))
         meas.append(np.stack([uL[idx], uR[idx], v[idx]], 1))
     obs_p, obs_l, meas = np.concatenate(obs_p), np.concatenate(obs_l), np.concatenate(meas)
     used = np.unique(obs_l)
@@ -265,9 +275,15 @@ def nav_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, kf_period=0.2, pose_sigma_t=
                     -4.5 + 9.0 * _hash_uniform(j, seed ^ 0x2222),
                     -(2.0 + 4.0 * _hash_uniform(j, seed ^ 0x3333))], 1)
     obs_p, obs_l, meas = [], [], []
+    # footprint cull along the track (see ba_sequence): |world dx| <= 960/fx * 6.2 * cos + 540/fy * 6.2 * sin < 4.5 m
+    x_order = np.argsort(pts[:, 0], kind="stable")
+    x_sorted = pts[x_order, 0]
     for i in range(n_kf):
         R = poses[i, :9].reshape(3, 3)
-        q = (pts - poses[i, 9:]) @ R
+        lo = np.searchsorted(x_sorted, poses[i, 9] - 4.5, "left")
+        hi = np.searchsorted(x_sorted, poses[i, 9] + 4.5, "right")
+        cand = np.sort(x_order[lo:hi])
+        q = (pts[cand] - poses[i, 9:]) @ R
         z = q[:, 2]
         with np.errstate(divide="ignore", invalid="ignore"):
             uL = cx + fx * q[:, 0] / z
@@ -278,7 +294,7 @@ def nav_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, kf_period=0.2, pose_sigma_t=
         if len(idx) > obs_per_kf:
             d2 = (uL[idx] - cx) ** 2 + (v[idx] - cy) ** 2
             idx = np.sort(idx[np.argsort(d2, kind="stable")[:obs_per_kf]])
-        obs_p.append(np.full(len(idx), i, np.int32)); obs_l.append(idx.astype(np.int32))
+        obs_p.append(np.full(len(idx), i, np.int32)); obs_l.append(cand[idx].astype(np.int32))
         meas.append(np.stack([uL[idx], uR[idx], v[idx]], 1))
     obs_p, obs_l, meas = np.concatenate(obs_p), np.concatenate(obs_l), np.concatenate(meas)
     used = np.unique(obs_l)
