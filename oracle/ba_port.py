@@ -24,8 +24,11 @@ def _structure(st):
 
 
 class BAPort:
-    def __init__(self, P, st, native=False):
+    def __init__(self, P, st, native=False, blas_threads=None):
+        """blas_threads: size of the BLAS pool during the LAPACK band solve only (None = leave it as set_threads()
+        made it).  OpenBLAS's dpbtrf does not always gain from more threads; bench.py calibrates this."""
         self.P, self.lib = P, O.lib(native=native)
+        self.blas_threads = blas_threads
         self.S, self._keep = _structure(st)
         self.band = int(st["band"])
         nP, nL, nO = P.n_poses, P.n_points, P.n_obs
@@ -69,7 +72,12 @@ class BAPort:
             except np.linalg.LinAlgError:
                 return None
             return sl.cho_solve_banded((c, True), -self.gs.reshape(-1), check_finite=False).reshape(-1, 6)
-        dp = self._timed("band_solve", run)
+        if self.blas_threads is not None:
+            import threadpoolctl
+            with threadpoolctl.threadpool_limits(limits=int(self.blas_threads), user_api="blas"):
+                dp = self._timed("band_solve", run)
+        else:
+            dp = self._timed("band_solve", run)
         return dp, dp is not None
 
     def backsub(self, dp):

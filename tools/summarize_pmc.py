@@ -21,18 +21,26 @@ if "--traffic-json" in sys.argv:
     import json
     i = sys.argv.index("--traffic-json")
     path, n_img = sys.argv[i + 1], int(sys.argv[i + 2])
-    res = {}
+    res, valu = {}, {}
     for k, cs in out.items():
+        kk = k.split("<")[0]
         if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
-            kk = k.split("<")[0]
             # gfx950: FETCH_SIZE reports half the bytes of coalesced streaming reads (MI355X_MICROARCH.md, HBM section);
             # calibrated here on fast_tile_kernel, which must read every image byte once: it reports 461 KB per
             # 921.6 KB image -> factor 2.
             f = 2.0 * sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024 / n_img
             w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024 / n_img
             res[kk] = {"fetch": f, "write": w}
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), bench.py --frames %d" % (n_img // 2),
+        if "SQ_INSTS_VALU" in cs:
+            valu[kk] = sum(cs["SQ_INSTS_VALU"]) / len(cs["SQ_INSTS_VALU"]) / n_img
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS_VALU (separate passes), bench.py --frames %d" % (n_img // 2),
                "note": "fetch = 2 x FETCH_SIZE (gfx950 under-reports coalesced streaming reads by 2x, MI355X_MICROARCH.md; "
                        "calibrated on fast_tile_kernel whose 921,600-byte image read shows as 461 KB); write = WRITE_SIZE; "
                        "hamming kernels: per image = per pair",
-               "bytes_per_image": res}, open(path, "w"), indent=1)
+               "bytes_per_image": res,
+               "valu_wave_insts_per_image": valu,
+               "valu_ns_per_wave_inst_per_simd": {"fast_tile_kernel": 1.7},
+               "valu_note": "SQ_INSTS_VALU per image; ns per wave-instruction per SIMD of fast_tile_kernel's instruction mix from "
+                            "tools/ubench/valu_rate.hip (profiles/valu_issue_rates_*.txt): v_min3/v_max3_i32, v_alignbyte, v_bfe, "
+                            "SDWA and v_dot4 issue at 1.7-1.85 ns, plain add/xor/and at 1.0-1.09 ns"},
+              open(path, "w"), indent=1)
