@@ -266,6 +266,19 @@ int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, do
 int vus_ba_band_solve_multi(double* Sband, int n_nodes, int band, double* rhs, int n_rhs, int* status,
                             void* stream);
 
+/* Two-sided variants of the two solves above: poses are eliminated from both ends of the band in the same launches
+ * (top-down in place, bottom-up on a pose-reversed copy held in `work`), the dense system of the >= band middle
+ * poses is solved in between, which halves the chain of dependent panel steps that bounds the solve.  Same result to
+ * round-off; Sband is overwritten (contents unspecified).  `work`: vus_ba_band_solve_work_doubles() doubles; that
+ * function returns 0 when the system is too short to split (n_nodes < band + 16): the calls then fall back to the
+ * one-sided solve and ignore `work` (which must still be non-NULL).  status: as above; a non-positive pivot is
+ * reported as SOME scalar column + 1 > 0 (the elimination order differs from the one-sided solve's). */
+long long vus_ba_band_solve_work_doubles(int n_nodes, int band, int n_rhs);
+int vus_ba_band_solve_split(double* Sband, int n_poses, int band, const double* gs, double* dp, int* status,
+                            double* work, void* stream);
+int vus_ba_band_solve_multi_split(double* Sband, int n_nodes, int band, double* rhs, int n_rhs, int* status,
+                                  double* work, void* stream);
+
 /* ---- navigation factors on the camera side (graphs with vus_nav_factors, pose_stride = 2) ----
  * vus_nav_linearize: residuals/Jacobians of every ImuFactor / DVL factor / velocity prior at
  * (poses, vels, bias), accumulated (in a fixed order) into

@@ -387,6 +387,20 @@ int vus_ba_band_solve_multi_cpu(double* Sband, int n_nodes, int band, double* rh
   return VUS_OK;
 }
 
+/* Twins of the two-sided solves: the oracle states WHAT is solved (S x = rhs), not in which order the GPU
+ * eliminates; `work` is ignored. */
+int vus_ba_band_solve_split_cpu(double* Sband, int n_poses, int band, const double* gs, double* dp, int* status,
+                                double* work) {
+  (void)work;
+  return vus_ba_band_solve_cpu(Sband, n_poses, band, gs, dp, status);
+}
+
+int vus_ba_band_solve_multi_split_cpu(double* Sband, int n_nodes, int band, double* rhs, int n_rhs, int* status,
+                                      double* work) {
+  (void)work;
+  return vus_ba_band_solve_multi_cpu(Sband, n_nodes, band, rhs, n_rhs, status);
+}
+
 int vus_ba_backsub_cpu(const vus_ba_problem* P, const double* W, const double* Vinv, const double* gl,
                        const double* dp, double* dl) {
   if (!P || !W || !Vinv || !gl || !dp || !dl) return VUS_E_INVALID;

@@ -270,3 +270,90 @@ def test_band_solve_with_several_row_groups_per_workgroup(gpu, oracle, monkeypat
     _lib.call("vus_ba_band_solve_multi", d_S.data_ptr(), nP, B, d_r.data_ptr(), 7, d_st.data_ptr(), _lib.current_stream_ptr())
     assert int(d_st.item()) == 0
     assert relerr(d_r.cpu().numpy(), np.linalg.solve(A, rhs.T).T) < 1e-10
+
+
+def _random_band_system(rng, nP, B):
+    n = 6 * nP
+    A = np.zeros((n, n))
+    for i in range(nP):
+        for k in range(max(0, i - B), i + 1):
+            A[6 * i:6 * i + 6, 6 * k:6 * k + 6] = rng.normal(size=(6, 6))
+    A = np.tril(A) + np.tril(A, -1).T
+    A += np.eye(n) * (np.abs(A).sum(1).max() + 1.0)
+    Sb = np.zeros((nP, B + 1, 36))
+    for i in range(nP):
+        for k in range(max(0, i - B), i + 1):
+            Sb[i, i - k] = A[6 * i:6 * i + 6, 6 * k:6 * k + 6].reshape(-1)
+    return A, Sb
+
+
+@pytest.mark.parametrize("max_wg", [None, "3"])
+def test_two_sided_band_solve_equals_dense_solve(gpu, oracle, monkeypatch, max_wg):
+    """vus_ba_band_solve_split / _multi_split: elimination from both ends of the band + dense middle system.  Random
+    SPD block bands of many shapes (middle exactly `band` poses or up to 15 more, band not a multiple of the panel,
+    systems too short to split -> fallback) against numpy; also with several row groups per workgroup forced."""
+    from visual_underwater_slam_amd import _lib
+    if max_wg:
+        monkeypatch.setenv("VUS_CB_MAX_WG", max_wg)
+    lib = _lib.load()
+    rng = np.random.default_rng(11)
+    for nP, B in [(33, 9), (97, 8), (131, 37), (200, 90), (260, 17), (64, 20), (57, 1), (500, 60), (40, 30), (20, 3), (333, 41)]:
+        A, Sb = _random_band_system(rng, nP, B)
+        n = 6 * nP
+        for n_rhs in (1, 7):
+            nw = int(lib.vus_ba_band_solve_work_doubles(nP, B, n_rhs))
+            assert (nw > 0) == (((nP - B) // 2 // 8) * 8 >= 8)
+            work = torch.empty(max(nw, 1), dtype=torch.float64, device="cuda")
+            d_S = torch.from_numpy(Sb).cuda()
+            d_st = torch.zeros(1, dtype=torch.int32, device="cuda")
+            if n_rhs == 1:
+                gs = rng.normal(size=(nP, 6))
+                d_g = torch.from_numpy(gs).cuda()
+                d_x = torch.empty((nP, 6), dtype=torch.float64, device="cuda")
+                _lib.call("vus_ba_band_solve_split", d_S.data_ptr(), nP, B, d_g.data_ptr(), d_x.data_ptr(), d_st.data_ptr(),
+                          work.data_ptr(), _lib.current_stream_ptr())
+                got, exp = d_x.cpu().numpy().reshape(-1), np.linalg.solve(A, -gs.reshape(-1))
+            else:
+                rhs = rng.normal(size=(n_rhs, n))
+                d_r = torch.from_numpy(rhs).cuda()
+                _lib.call("vus_ba_band_solve_multi_split", d_S.data_ptr(), nP, B, d_r.data_ptr(), n_rhs, d_st.data_ptr(),
+                          work.data_ptr(), _lib.current_stream_ptr())
+                got, exp = d_r.cpu().numpy(), np.linalg.solve(A, rhs.T).T
+            assert int(d_st.item()) == 0, (nP, B, n_rhs)
+            assert relerr(got, exp) < 1e-10, (nP, B, n_rhs)
+
+
+def test_two_sided_band_solve_reports_indefinite_systems(gpu):
+    """A non-positive pivot anywhere -- top half, bottom half or middle -- gives status > 0."""
+    from visual_underwater_slam_amd import _lib
+    lib = _lib.load()
+    nP, B = 120, 10
+    for bad_pose in (5, 60, 115):
+        Sb = np.zeros((nP, B + 1, 36))
+        for i in range(nP):
+            Sb[i, 0] = (4.0 * np.eye(6)).reshape(-1)
+        Sb[bad_pose, 0, 21] = -1.0
+        nw = int(lib.vus_ba_band_solve_work_doubles(nP, B, 1))
+        assert nw > 0
+        work = torch.empty(nw, dtype=torch.float64, device="cuda")
+        d_S = torch.from_numpy(Sb).cuda(); d_g = torch.ones((nP, 6), dtype=torch.float64, device="cuda")
+        d_x = torch.empty((nP, 6), dtype=torch.float64, device="cuda")
+        d_st = torch.zeros(1, dtype=torch.int32, device="cuda")
+        _lib.call("vus_ba_band_solve_split", d_S.data_ptr(), nP, B, d_g.data_ptr(), d_x.data_ptr(), d_st.data_ptr(),
+                  work.data_ptr(), _lib.current_stream_ptr())
+        assert int(d_st.item()) == 6 * bad_pose + 3 + 1, bad_pose
+
+
+def test_two_sided_solve_inside_the_lm_gives_the_one_sided_result(gpu, oracle):
+    """StereoBASolver picks the two-sided solve for long trajectories; same LM trajectory and optimum as with the
+    one-sided solve (and hence as the oracle, test_lm_matches_oracle_trajectory_and_result)."""
+    s, prob, sv, P = setup(oracle, 300, 6000, 300)
+    assert sv.use_split and prob.n_poses >= 2 * prob.band + 64
+    p0, x0 = torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda()
+    poses2, points2, rep2 = sv.optimize(p0, x0)
+    sv.use_split = False
+    poses1, points1, rep1 = sv.optimize(p0, x0)
+    assert (rep1.iterations, rep1.tries, rep1.status) == (rep2.iterations, rep2.tries, rep2.status)
+    assert np.allclose(rep1.err_hist, rep2.err_hist, rtol=1e-9)
+    assert relerr(poses2.cpu().numpy(), poses1.cpu().numpy()) < 1e-8
+    assert relerr(points2.cpu().numpy(), points1.cpu().numpy()) < 1e-7

@@ -32,6 +32,8 @@ SIGNATURES = {
     "vus_ba_eval_step": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "vus_ba_error": [_P, _P, _P, _P, _P, _P],
     "vus_ba_band_solve_multi": [_P, c_int, c_int, _P, c_int, _P, _P],
+    "vus_ba_band_solve_split": [_P, c_int, c_int, _P, _P, _P, _P, _P],
+    "vus_ba_band_solve_multi_split": [_P, c_int, c_int, _P, c_int, _P, _P, _P],
     # navigation factors
     "vus_nav_linearize": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "vus_nav_assemble": [c_int, c_int, c_double, _P, _P, _P, _P, _P, _P, _P],
@@ -69,6 +71,8 @@ def load():
         fn.restype = c_int
     lib.vus_ba_work_doubles.argtypes = [_P]
     lib.vus_ba_work_doubles.restype = ctypes.c_longlong
+    lib.vus_ba_band_solve_work_doubles.argtypes = [c_int, c_int, c_int]
+    lib.vus_ba_band_solve_work_doubles.restype = ctypes.c_longlong
     lib.vus_nav_work_doubles.argtypes = [_P]
     lib.vus_nav_work_doubles.restype = ctypes.c_longlong
     _lib = lib

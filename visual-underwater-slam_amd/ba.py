@@ -144,6 +144,18 @@ class StereoBASolver:
         self.work = torch.empty((2 * (nL + 1) + 8,), **f64)
         self.scal = torch.zeros((4,), **f64)          # [0] linearise error, [1] lin. error at step, [2] new error
         self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        # two-sided band solve (vus_ba_band_solve_split): worth it once the chain of panel steps is much longer than
+        # the band; its workspace (pose-reversed copy of the lower half + the middle system) is allocated once
+        self.band_rhs = 1
+        self._alloc_band_work()
+
+    SPLIT_MIN_EXTRA = 64       # use the two-sided solve when n_nodes >= 2 * band + this
+
+    def _alloc_band_work(self):
+        nN, B = self.P.n_nodes, self.P.band
+        n = int(_lib.load().vus_ba_band_solve_work_doubles(nN, B, self.band_rhs))
+        self.use_split = n > 0 and nN >= 2 * B + self.SPLIT_MIN_EXTRA
+        self.band_work = torch.empty((n if self.use_split else 0,), dtype=torch.float64, device=self.P.device)
 
     # -- single kernels (also used by the parity tests) ------------------------------------------
     def _pp(self):
@@ -167,8 +179,12 @@ class StereoBASolver:
 
     def band_solve(self):
         p = _lib.ptr
-        _lib.call("vus_ba_band_solve", p(self.Sband), self.P.n_nodes, self.P.band, p(self.gs), p(self.dp),
-                  p(self.status), _lib.current_stream_ptr())
+        if self.use_split:
+            _lib.call("vus_ba_band_solve_split", p(self.Sband), self.P.n_nodes, self.P.band, p(self.gs), p(self.dp),
+                      p(self.status), p(self.band_work), _lib.current_stream_ptr())
+        else:
+            _lib.call("vus_ba_band_solve", p(self.Sband), self.P.n_nodes, self.P.band, p(self.gs), p(self.dp),
+                      p(self.status), _lib.current_stream_ptr())
 
     def backsub(self):
         p = _lib.ptr
@@ -318,6 +334,8 @@ class NavBASolver(StereoBASolver):
         if problem.pose_stride != 2:
             raise ValueError("NavBASolver needs a StereoBAProblem built with pose_stride=2")
         super().__init__(problem)
+        self.band_rhs = 7
+        self._alloc_band_work()
         self.N = nav
         dev, nP, nN = problem.device, problem.n_poses, problem.n_nodes
         f64 = dict(dtype=torch.float64, device=dev)
@@ -353,7 +371,11 @@ class NavBASolver(StereoBASolver):
     def nav_solve(self, lam):
         p = _lib.ptr
         st = _lib.current_stream_ptr()
-        _lib.call("vus_ba_band_solve_multi", p(self.Sband), self.P.n_nodes, self.P.band, p(self.rhs), 7, p(self.status), st)
+        if self.use_split:
+            _lib.call("vus_ba_band_solve_multi_split", p(self.Sband), self.P.n_nodes, self.P.band, p(self.rhs), 7,
+                      p(self.status), p(self.band_work), st)
+        else:
+            _lib.call("vus_ba_band_solve_multi", p(self.Sband), self.P.n_nodes, self.P.band, p(self.rhs), 7, p(self.status), st)
         _lib.call("vus_nav_border_solve", self.P.n_nodes, p(self.rhs), p(self.Scb), p(self.Sbb), p(self.gb), float(lam),
                   p(self.dp), p(self.db), st)
 

@@ -748,12 +748,26 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
   }
 }
 
-__global__ __launch_bounds__(256) void chol_panel_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
-                                                         double* __restrict__ yv, size_t ystride, int n_rhs,
-                                                         int* __restrict__ status) {
+// One block-band system handed to the factorisation kernels: storage, right-hand sides [n_rhs, 6 n] (solved in
+// place), status word, flag area of the cooperative sweep, number of poses.  A launch serves one system, or two
+// of identical geometry interleaved block by block (the two halves of the two-sided solve, see band_solve_split).
+struct BandSys {
+  double* Sb;
+  double* y;
+  int* status;
+  int* F;
+  int n;
+};
+struct BandSet {
+  BandSys s[2];
+  int count;
+};
+
+__global__ __launch_bounds__(256) void chol_panel_kernel(BandSet S, int band, int k0, int n_rhs) {
   __shared__ __attribute__((aligned(16))) double s_x[3][64 * 6];
   __shared__ int s_bad;
-  panel_factor<false>(Sb, n_poses, band, k0, yv, ystride, n_rhs, status, s_x, s_bad);
+  const BandSys B = S.s[blockIdx.x];
+  panel_factor<false>(B.Sb, B.n, band, k0, B.y, 6 * (size_t)B.n, n_rhs, B.status, s_x, s_bad);
 }
 
 // Rows below the panel, fused with the trailing update.  X = A_rows,panel * L_D^-T is what a TRSM
@@ -957,9 +971,8 @@ __device__ __forceinline__ void stage_and_solve(const double* __restrict__ Sb, i
   VUS_TMARK(4);
 }
 
-__global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restrict__ Sb, int n_poses, int band, int k0,
-                                                               int n_update, int k0_prev, double* __restrict__ yv,
-                                                               size_t ystride, int n_rhs, int* __restrict__ status) {
+__global__ __launch_bounds__(256) void chol_trsm_update_kernel(BandSet S, int band, int k0, int n_update, int k0_prev,
+                                                               int n_rhs, int factor_next) {
   __shared__ __attribute__((aligned(16))) double Xi[UT * ULD];
   __shared__ double Xj[UT * ULD];
   __shared__ double sL[NB * LDD];
@@ -968,9 +981,18 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
   __shared__ int s_bad;
   VUS_TMARK(0);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if ((int)blockIdx.x >= n_update) {
+  // two systems: even blocks serve system 0, odd blocks system 1, so that both critical workgroups (bid 0) are
+  // among the first blocks dispatched
+  const int sysi = S.count == 2 ? (int)(blockIdx.x & 1) : 0;
+  const int bid = S.count == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+  double* __restrict__ Sb = S.s[sysi].Sb;
+  double* __restrict__ yv = S.s[sysi].y;
+  int* __restrict__ status = S.s[sysi].status;
+  const int n_poses = S.s[sysi].n;
+  const size_t ystride = 6 * (size_t)n_poses;
+  if (bid >= n_update) {
     // write-back of the previous panel's rows: tile t of its window
-    const int t = (int)blockIdx.x - n_update;
+    const int t = bid - n_update;
     const int pbp = min(PB, n_poses - k0_prev);
     const int i_first = k0_prev + pbp;
     const int i_last = min(n_poses - 1, k0_prev + pbp - 1 + band);
@@ -995,10 +1017,10 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
   const int i_first = k0 + pb;
   const int i_last = min(n_poses - 1, k0 + pb - 1 + band);
   // tile (ti, tj), tj <= ti, from the linear block index
-  int ti = (int)((sqrtf(8.0f * (float)blockIdx.x + 1.0f) - 1.0f) * 0.5f);
-  while ((ti + 1) * (ti + 2) / 2 <= (int)blockIdx.x) ++ti;
-  while (ti * (ti + 1) / 2 > (int)blockIdx.x) --ti;
-  const int tj = (int)blockIdx.x - ti * (ti + 1) / 2;
+  int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+  while (ti * (ti + 1) / 2 > bid) --ti;
+  const int tj = bid - ti * (ti + 1) / 2;
   const int pi0 = i_first + ti * UTP, pj0 = i_first + tj * UTP;   // first pose of the tile rows / columns
   const double* Xjj = (ti == tj) ? Xi : Xj;
   const int arow = lane & 15, kq = lane >> 4;
@@ -1056,7 +1078,7 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
 #pragma unroll
     for (int r = 0; r < 4; ++r)
       if (ok[q][r]) Sb[off[q][r]] = -acc[q][r];
-    if (blockIdx.x == 0) {   // tile (0,0) also leaves its result in LDS (sL is free) for the panel factorisation below
+    if (bid == 0 && factor_next) {   // tile (0,0) also leaves its result in LDS (sL is free) for the panel factorisation below
       const int Cc = 16 * b + arow;
 #pragma unroll
       for (int r = 0; r < 4; ++r) sL[(16 * a + kq + 4 * r) * LDD + Cc] = -acc[q][r];
@@ -1073,11 +1095,11 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(double* __restric
         for (int c = 0; c < NB; ++c) acc += Xi[tid * ULD + c] * Xj[NB * q + c];
         const double ynew = yq[6 * (size_t)i + (tid % 6)] - acc;
         yq[6 * (size_t)i + (tid % 6)] = ynew;
-        if (blockIdx.x == 0) Xj[NB * BS_RHS_MAX + NB * q + tid] = ynew;   // the next panel's right-hand-side rows
+        if (bid == 0 && factor_next) Xj[NB * BS_RHS_MAX + NB * q + tid] = ynew;   // the next panel's right-hand-side rows
       }
   }
   VUS_TMARK(7);
-  if (blockIdx.x == 0) {
+  if (bid == 0 && factor_next) {
     // Tile (0,0) is the next panel's diagonal block, complete once this workgroup has stored it: factor it
     // here instead of in a launch of its own (the other ~400 workgroups of this launch take as long anyway).
     __syncthreads();                   // the LDS copies are complete; the X tiles in LDS are dead
@@ -1159,12 +1181,22 @@ __device__ __forceinline__ void cb_load_diag(const double* __restrict__ Sb, int 
   for (int c = 0; c < NB; ++c) Lp[c] *= dinv;
 }
 
-__global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(const double* __restrict__ Sb, int n_poses,
-                                                                    int band, double* yv, size_t ystride, int n_rhs,
-                                                                    int n_groups, int* F, int* __restrict__ status) {
+__global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, int band, int n_rhs, int n_groups, int n_solve) {
   if (blockIdx.x & 7) return;
-  const int g = blockIdx.x >> 3;                 // workgroup index: 0 = solver, w >= 1 serves row groups w, w + n_wg - 1, ...
-  const int n_helpers = (int)(gridDim.x >> 3) - 1;
+  // workgroup index g inside its system: 0 = solver, w >= 1 serves row groups w, w + n_wg - 1, ...; with two systems
+  // (the two halves of the two-sided solve) consecutive working blocks alternate between them
+  const int wg = blockIdx.x >> 3;
+  const int sysi = S.count == 2 ? (wg & 1) : 0;
+  const int g = S.count == 2 ? (wg >> 1) : wg;
+  const int n_helpers = (int)(gridDim.x >> 3) / S.count - 1;
+  const double* __restrict__ Sb = S.s[sysi].Sb;
+  double* yv = S.s[sysi].y;
+  int* F = S.s[sysi].F;
+  int* __restrict__ status = S.s[sysi].status;
+  // n_solve > 0: only the leading n_solve poses are back-substituted (the eliminated part of a partial factorisation);
+  // the right-hand sides keep the row stride of the whole system
+  const int n_poses = n_solve > 0 ? n_solve : S.s[sysi].n;
+  const size_t ystride = 6 * (size_t)S.s[sysi].n;
   __shared__ double s_x[BS_MAX_RHS][NB];
   __shared__ double s_part[BS_MAX_RHS][PB][NB];
   __shared__ double s_own[BS_MAX_RHS][NB];
@@ -1550,38 +1582,248 @@ int backsolve_max_wg() {
   return cap;
 }
 
-int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, int* status, hipStream_t st) {
-  const size_t ystride = 6 * (size_t)n_nodes;
-  VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+// Right-looking factorisation launches for the systems of S (identical geometry): panels 0 .. n_elim/PB - 1 are
+// eliminated (n_elim == S.s[0].n: the whole matrix; smaller, a multiple of PB: a PARTIAL factorisation that leaves the
+// Schur complement of the eliminated poses in the trailing window and the forward-substituted right-hand sides
+// in y).  The forward substitution rides along.
+int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st) {
+  const int n = S.s[0].n, c = S.count;
+  const bool full = n_elim >= n;
   int k0_prev = -1, tiles_prev = 0;
-  for (int k0 = 0; k0 < n_nodes; k0 += PB) {
+  for (int k0 = 0; k0 < (full ? n : n_elim); k0 += PB) {
     // panel 0 has a launch of its own; panel p + 1 is factored by tile (0,0) of panel p's update launch
-    if (k0 == 0) chol_panel_kernel<<<1, 256, 0, st>>>(Sband, n_nodes, band, k0, y, ystride, n_rhs, status);
-    const int pb = n_nodes - k0 < PB ? n_nodes - k0 : PB;
+    if (k0 == 0) chol_panel_kernel<<<c, 256, 0, st>>>(S, band, k0, n_rhs);
+    const int pb = n - k0 < PB ? n - k0 : PB;
     const int i_first = k0 + pb;
     int i_last = k0 + pb - 1 + band;
-    if (i_last > n_nodes - 1) i_last = n_nodes - 1;
+    if (i_last > n - 1) i_last = n - 1;
     const int rows = i_last - i_first + 1;
     const int tiles = rows > 0 ? (rows + UTP - 1) / UTP : 0;
     const int n_update = tiles * (tiles + 1) / 2;
+    const int factor_next = (full || k0 + PB < n_elim) ? 1 : 0;
     // update tiles of this panel + the write-back of the previous panel's solved rows
     if (n_update + tiles_prev > 0)
-      chol_trsm_update_kernel<<<n_update + tiles_prev, 256, 0, st>>>(Sband, n_nodes, band, k0, n_update, k0_prev, y,
-                                                                   ystride, n_rhs, status);
+      chol_trsm_update_kernel<<<c * (n_update + tiles_prev), 256, 0, st>>>(S, band, k0, n_update, k0_prev, n_rhs, factor_next);
     k0_prev = k0;
     tiles_prev = tiles;
   }
+  if (!full && tiles_prev > 0)   // write-back of the last eliminated panel's solved rows
+    chol_trsm_update_kernel<<<c * tiles_prev, 256, 0, st>>>(S, band, n_elim, 0, k0_prev, n_rhs, 0);
+  VUS_CHECK_LAUNCH("ba_band_factor");
+  return VUS_OK;
+}
+
+// Cooperative back-substitution x = L^-T y of every system of S (n_solve > 0: of its leading n_solve poses only).
+int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st) {
   // flags of the cooperative sweep live in the unused slots of block row 0 (blocks (0, k < 0))
   const int n_groups = band > 0 ? (band + PB - 1) / PB : 1;
-  int* F = band > 0 ? reinterpret_cast<int*>(Sband + 36) : flags_fallback();
-  VUS_REQUIRE(F != nullptr, "no scratch for the solver flags");
   VUS_REQUIRE(band == 0 || 2 + n_groups <= 72 * band, "band=%d: too many row groups for the flag area", band);
-  VUS_CHECK_HIP(hipMemsetAsync(F, 0, sizeof(int) * (size_t)(2 + n_groups), st));
-  // at most backsolve_max_wg() cooperating workgroups, so that all of them are resident at once
-  const int max_wg = backsolve_max_wg();
+  for (int q = 0; q < S.count; ++q) {
+    S.s[q].F = band > 0 ? reinterpret_cast<int*>(S.s[q].Sb + 36) : flags_fallback();
+    VUS_REQUIRE(S.s[q].F != nullptr, "no scratch for the solver flags");
+    VUS_REQUIRE(band > 0 || S.count == 1, "two band-0 systems cannot share the fallback flags");
+    VUS_CHECK_HIP(hipMemsetAsync(S.s[q].F, 0, sizeof(int) * (size_t)(2 + n_groups), st));
+  }
+  // at most backsolve_max_wg() cooperating workgroups in total, so that all of them are resident at once
+  int max_wg = backsolve_max_wg() / S.count;
+  if (max_wg < 1) max_wg = 1;
   const int n_wg = n_groups < max_wg ? n_groups : max_wg;
-  chol_backsolve_kernel<<<8 * n_wg, CB_THREADS, 0, st>>>(Sband, n_nodes, band, y, ystride, n_rhs, n_groups, F, status);
-  VUS_CHECK_LAUNCH("ba_band_solve");
+  chol_backsolve_kernel<<<8 * n_wg * S.count, CB_THREADS, 0, st>>>(S, band, n_rhs, n_groups, n_solve);
+  VUS_CHECK_LAUNCH("ba_band_backsolve");
+  return VUS_OK;
+}
+
+int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, int* status, hipStream_t st) {
+  VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+  BandSet S;
+  S.count = 1;
+  S.s[0] = BandSys{Sband, y, status, nullptr, n_nodes};
+  S.s[1] = S.s[0];
+  if (int rc = factor_launches(S, band, n_nodes, n_rhs, st)) return rc;
+  return backsolve_launch(S, band, n_rhs, 0, st);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two-sided ("burn at both ends") solve.  The factorisation is a chain of n/8 dependent panel steps, each as long
+// as one workgroup's dependent work (the launch is latency-bound, not flop-bound), so the chain is cut in two:
+// poses 0 .. m-1 are eliminated top-down in place (system T = the first m + band block rows of Sband), poses
+// n-1 .. n-m bottom-up on a pose-reversed copy (system R), both in the SAME launches, block-interleaved; what is
+// left is the dense system of the n - 2m middle poses (>= band of them): its entries are the T window (updated in
+// place, original entries included) plus R's window (started from zero: Schur contributions only).  It is factored
+// and solved one-sided, its solution is pushed through the two "spikes" (the factor blocks that couple the middle
+// to the last eliminated poses of either side) and both halves are back-substituted in one cooperative launch.
+// Same arithmetic, the elimination order differs: results agree with the one-sided solve to round-off.
+struct SplitPlan {
+  int n, band, n_rhs, m, nT, n_mid, bm;
+  size_t off_R, off_mid, off_yT, off_yR, off_yM, off_int, total;
+};
+
+bool split_plan(int n, int band, int n_rhs, SplitPlan& p) {
+  p.n = n; p.band = band; p.n_rhs = n_rhs;
+  p.m = band > 0 ? ((n - band) / 2 / PB) * PB : 0;
+  if (p.m < PB) return false;
+  p.nT = p.m + band;
+  p.n_mid = n - 2 * p.m;
+  p.bm = band < p.n_mid - 1 ? band : p.n_mid - 1;
+  size_t o = 0;
+  p.off_R = o;   o += 36 * (size_t)p.nT * (band + 1);
+  p.off_mid = o; o += 36 * (size_t)p.n_mid * (p.bm + 1);
+  p.off_yT = o;  o += 6 * (size_t)p.nT * n_rhs;
+  p.off_yR = o;  o += 6 * (size_t)p.nT * n_rhs;
+  p.off_yM = o;  o += 6 * (size_t)p.n_mid * n_rhs;
+  p.off_int = o; o += 8;
+  p.total = o;
+  return true;
+}
+
+// Rb(i', s) = transpose of Sband(n-1-i'+s, s) -- the pose-reversed matrix in the same lower-band layout -- except the
+// middle x middle region (both reversed poses >= m), which starts from zero; yT = y[.. nT), yR = reversed y, zero on
+// the middle poses.
+__global__ void split_prepare_kernel(const double* __restrict__ Sband, const double* __restrict__ y, SplitPlan p,
+                                     double* __restrict__ Rb, double* __restrict__ yT, double* __restrict__ yR) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t nR = 36 * (size_t)p.nT * (p.band + 1);
+  if (t < nR) {
+    const int e = (int)(t % 36);
+    const size_t blk = t / 36;
+    const int s = (int)(blk % (p.band + 1)), ip = (int)(blk / (p.band + 1));
+    const int kp = ip - s;
+    double v = 0.0;
+    if (kp >= 0 && kp < p.m) {
+      const int r = e / 6, c = e - 6 * r;
+      v = Sband[36 * ((size_t)(p.n - 1 - kp) * (p.band + 1) + s) + 6 * c + r];
+    }
+    Rb[t] = v;
+  }
+  const size_t ny = 6 * (size_t)p.nT * p.n_rhs;
+  if (t < ny) {
+    const int q = (int)(t / (6 * (size_t)p.nT)), rem = (int)(t - (size_t)q * 6 * p.nT);
+    const int i = rem / 6, c = rem - 6 * i;
+    const double* yq = y + (size_t)q * 6 * p.n;
+    yT[t] = yq[6 * (size_t)i + c];
+    yR[t] = i < p.m ? yq[6 * (size_t)(p.n - 1 - i) + c] : 0.0;
+  }
+}
+
+// Mid(u, s) = Sband(m + u, s) [T's window, or untouched original rows past it] + transpose of R's window block;
+// diagonal blocks are symmetrised (the factorisation maintains their lower triangles only).  yM likewise.
+__global__ void split_mid_kernel(const double* __restrict__ Sband, const double* __restrict__ y, SplitPlan p,
+                                 const double* __restrict__ Rb, const double* __restrict__ yT,
+                                 const double* __restrict__ yR, double* __restrict__ Mid, double* __restrict__ yM) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  const size_t nM = 36 * (size_t)p.n_mid * (p.bm + 1);
+  if (t < nM) {
+    const int e = (int)(t % 36);
+    const size_t blk = t / 36;
+    const int s = (int)(blk % (p.bm + 1)), u = (int)(blk / (p.bm + 1));
+    int r = e / 6, c = e - 6 * r;
+    double v = 0.0;
+    if (s <= u) {
+      if (s == 0 && c > r) { const int tmp = r; r = c; c = tmp; }     // mirror the lower triangle of a diagonal block
+      v = Sband[36 * ((size_t)(p.m + u) * (p.band + 1) + s) + 6 * r + c];
+      const int ip = p.n - 1 - (p.m + u - s);                          // reversed index of the block's column pose
+      if (ip < p.nT) {
+        const size_t rb = 36 * ((size_t)ip * (p.band + 1) + s);
+        v += s == 0 ? Rb[rb + 6 * r + c] : Rb[rb + 6 * c + r];
+      }
+    }
+    Mid[t] = v;
+  }
+  const size_t ny = 6 * (size_t)p.n_mid * p.n_rhs;
+  if (t < ny) {
+    const int q = (int)(t / (6 * (size_t)p.n_mid)), rem = (int)(t - (size_t)q * 6 * p.n_mid);
+    const int u = rem / 6, c = rem - 6 * u;
+    const int i = p.m + u, ip = p.n - 1 - i;
+    double v = i < p.nT ? yT[(size_t)q * 6 * p.nT + 6 * (size_t)i + c] : y[(size_t)q * 6 * p.n + 6 * (size_t)i + c];
+    if (ip < p.nT) v += yR[(size_t)q * 6 * p.nT + 6 * (size_t)ip + c];
+    yM[t] = v;
+  }
+}
+
+// y_k -= sum_{i >= m, i - k <= band} L(i, k)^T x_i for the eliminated poses k < m next to the middle, both systems
+// (blockIdx.y).  The blocks (i >= m, k < m) lie left of pose i's diagonal panel: stored transposed, so that
+// (L^T x)[c] = sum_r stored[6 c + r] x[r].  One wave per (pose k, right-hand side); lanes split (i, c).
+__global__ __launch_bounds__(64) void split_spike_kernel(const double* __restrict__ Sband, const double* __restrict__ Rb,
+                                                         SplitPlan p, const double* __restrict__ yM,
+                                                         double* __restrict__ yT, double* __restrict__ yR) {
+  const int sysi = blockIdx.y, q = blockIdx.z;
+  const int k = p.m - 1 - (int)blockIdx.x;
+  if (k < 0) return;
+  const double* Sb = sysi == 0 ? Sband : Rb;
+  double* ys = (sysi == 0 ? yT : yR) + (size_t)q * 6 * p.nT;
+  const double* xm = yM + (size_t)q * 6 * p.n_mid;
+  const int lane = threadIdx.x, c = lane % 6, sl = lane / 6;     // 10 slices of poses x 6 outputs (lanes 60..63 idle)
+  const int i_hi = min(k + p.band, p.nT - 1);
+  double acc = 0.0;
+  if (sl < 10)
+    for (int i = p.m + sl; i <= i_hi; i += 10) {
+      const double* b = Sb + 36 * ((size_t)i * (p.band + 1) + (i - k)) + 6 * c;
+      const int u = sysi == 0 ? i - p.m : p.n - 1 - i - p.m;       // middle index of (reversed) pose i
+      const double* x = xm + 6 * (size_t)u;
+      acc += b[0] * x[0] + b[1] * x[1] + b[2] * x[2] + b[3] * x[3] + b[4] * x[4] + b[5] * x[5];
+    }
+  __shared__ double s_acc[64];
+  s_acc[lane] = sl < 10 ? acc : 0.0;
+  __syncthreads();
+  if (lane < 6) {
+    double t = 0.0;
+    for (int j = 0; j < 10; ++j) t += s_acc[6 * j + lane];
+    ys[6 * (size_t)k + lane] -= t;
+  }
+}
+
+__global__ void split_gather_kernel(SplitPlan p, const double* __restrict__ yT, const double* __restrict__ yR,
+                                    const double* __restrict__ yM, double* __restrict__ y, const int* __restrict__ st_R,
+                                    const int* __restrict__ st_M, int* __restrict__ status) {
+  const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (t < 6 * (size_t)p.n * p.n_rhs) {
+    const int q = (int)(t / (6 * (size_t)p.n)), rem = (int)(t - (size_t)q * 6 * p.n);
+    const int i = rem / 6, c = rem - 6 * i;
+    double v;
+    if (i < p.m) v = yT[(size_t)q * 6 * p.nT + 6 * (size_t)i + c];
+    else if (i < p.n - p.m) v = yM[(size_t)q * 6 * p.n_mid + 6 * (size_t)(i - p.m) + c];
+    else v = yR[(size_t)q * 6 * p.nT + 6 * (size_t)(p.n - 1 - i) + c];
+    y[t] = v;
+  }
+  if (t == 0) {
+    // worst status of the three systems: an expired wait (-1) first, else the first non-positive pivot met, reported
+    // as a global scalar column + 1 (the column inside its own system for T, mapped back for R and the middle)
+    const int a = status[0], b = st_R[0], c = st_M[0];
+    int out = a;
+    if (a < 0 || b < 0 || c < 0) out = -1;
+    else if (a == 0 && b > 0) out = 6 * (p.n - 1 - (b - 1) / 6) + (b - 1) % 6 + 1;
+    else if (a == 0 && c > 0) out = 6 * p.m + c;
+    status[0] = out;
+  }
+}
+
+int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, int* status, double* work, hipStream_t st) {
+  SplitPlan p;
+  if (!split_plan(n, band, n_rhs, p)) return band_solve_impl(Sband, n, band, y, n_rhs, status, st);
+  double* Rb = work + p.off_R;
+  double* Mid = work + p.off_mid;
+  double* yT = work + p.off_yT;
+  double* yR = work + p.off_yR;
+  double* yM = work + p.off_yM;
+  int* st_R = reinterpret_cast<int*>(work + p.off_int);
+  int* st_M = st_R + 2;
+  VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+  VUS_CHECK_HIP(hipMemsetAsync(st_R, 0, 4 * sizeof(int), st));
+  const size_t nR = 36 * (size_t)p.nT * (band + 1);
+  split_prepare_kernel<<<cdiv((long long)nR, 256), 256, 0, st>>>(Sband, y, p, Rb, yT, yR);
+  BandSet S;
+  S.count = 2;
+  S.s[0] = BandSys{Sband, yT, status, nullptr, p.nT};
+  S.s[1] = BandSys{Rb, yR, st_R, nullptr, p.nT};
+  if (int rc = factor_launches(S, band, p.m, n_rhs, st)) return rc;
+  const size_t nM = 36 * (size_t)p.n_mid * (p.bm + 1);
+  split_mid_kernel<<<cdiv((long long)nM, 256), 256, 0, st>>>(Sband, y, p, Rb, yT, yR, Mid, yM);
+  if (int rc = band_solve_impl(Mid, p.n_mid, p.bm, yM, n_rhs, st_M, st)) return rc;
+  const int n_spike = band < p.m ? band : p.m;
+  split_spike_kernel<<<dim3(n_spike, 2, n_rhs), 64, 0, st>>>(Sband, Rb, p, yM, yT, yR);
+  if (int rc = backsolve_launch(S, band, n_rhs, p.m, st)) return rc;     // the eliminated poses of both halves
+  split_gather_kernel<<<cdiv(6ll * n * n_rhs, 256), 256, 0, st>>>(p, yT, yR, yM, y, st_R, st_M, status);
+  VUS_CHECK_LAUNCH("ba_band_solve_split");
   return VUS_OK;
 }
 }  // namespace
@@ -1601,6 +1843,29 @@ extern "C" int vus_ba_band_solve_multi(double* Sband, int n_nodes, int band, dou
   VUS_REQUIRE(n_nodes >= 1 && band >= 0, "n_nodes=%d band=%d", n_nodes, band);
   VUS_REQUIRE(n_rhs >= 1 && n_rhs <= BS_MAX_RHS, "n_rhs=%d out of range [1, %d]", n_rhs, BS_MAX_RHS);
   return band_solve_impl(Sband, n_nodes, band, rhs, n_rhs, status, vus::as_stream(stream));
+}
+
+extern "C" long long vus_ba_band_solve_work_doubles(int n_nodes, int band, int n_rhs) {
+  SplitPlan p;
+  if (n_nodes < 1 || band < 0 || n_rhs < 1 || n_rhs > BS_MAX_RHS || !split_plan(n_nodes, band, n_rhs, p)) return 0;
+  return (long long)p.total;
+}
+
+extern "C" int vus_ba_band_solve_split(double* Sband, int n_poses, int band, const double* gs, double* dp, int* status,
+                                       double* work, void* stream) {
+  VUS_REQUIRE(Sband && gs && dp && status && work, "null buffer");
+  VUS_REQUIRE(n_poses >= 1 && band >= 0, "n_poses=%d band=%d", n_poses, band);
+  hipStream_t st = vus::as_stream(stream);
+  negate_copy_kernel<<<cdiv(6ll * n_poses, 256), 256, 0, st>>>(gs, dp, 6 * n_poses);
+  return band_solve_split_impl(Sband, n_poses, band, dp, 1, status, work, st);
+}
+
+extern "C" int vus_ba_band_solve_multi_split(double* Sband, int n_nodes, int band, double* rhs, int n_rhs, int* status,
+                                             double* work, void* stream) {
+  VUS_REQUIRE(Sband && rhs && status && work, "null buffer");
+  VUS_REQUIRE(n_nodes >= 1 && band >= 0, "n_nodes=%d band=%d", n_nodes, band);
+  VUS_REQUIRE(n_rhs >= 1 && n_rhs <= BS_MAX_RHS, "n_rhs=%d out of range [1, %d]", n_rhs, BS_MAX_RHS);
+  return band_solve_split_impl(Sband, n_nodes, band, rhs, n_rhs, status, work, vus::as_stream(stream));
 }
 
 extern "C" int vus_ba_backsub(const vus_ba_problem* P, const double* W, const double* Vinv, const double* gl,
