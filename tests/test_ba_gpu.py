@@ -347,7 +347,7 @@ def test_two_sided_band_solve_reports_indefinite_systems(gpu):
 def test_two_sided_solve_inside_the_lm_gives_the_one_sided_result(gpu, oracle):
     """StereoBASolver picks the two-sided solve for long trajectories; same LM trajectory and optimum as with the
     one-sided solve (and hence as the oracle, test_lm_matches_oracle_trajectory_and_result)."""
-    s, prob, sv, P = setup(oracle, 300, 6000, 300)
+    s, prob, sv, P = setup(oracle, 300, 6000, 300, line_len=8)       # band 39 pose blocks
     assert sv.use_split and prob.n_poses >= 2 * prob.band + 64
     p0, x0 = torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda()
     poses2, points2, rep2 = sv.optimize(p0, x0)

@@ -1626,7 +1626,7 @@ int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st
   }
   // at most backsolve_max_wg() cooperating workgroups in total, so that all of them are resident at once
   int max_wg = backsolve_max_wg() / S.count;
-  if (max_wg < 1) max_wg = 1;
+  if (max_wg < 2) max_wg = 2;       // a solver and at least one helper per system (the helper then serves every row group)
   const int n_wg = n_groups < max_wg ? n_groups : max_wg;
   chol_backsolve_kernel<<<8 * n_wg * S.count, CB_THREADS, 0, st>>>(S, band, n_rhs, n_groups, n_solve);
   VUS_CHECK_LAUNCH("ba_band_backsolve");
