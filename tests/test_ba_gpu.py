@@ -287,14 +287,16 @@ def _random_band_system(rng, nP, B):
     return A, Sb
 
 
-@pytest.mark.parametrize("max_wg", [None, "3"])
-def test_two_sided_band_solve_equals_dense_solve(gpu, oracle, monkeypatch, max_wg):
+@pytest.mark.parametrize("max_wg,two_launch", [(None, None), ("3", None), (None, "0")])
+def test_two_sided_band_solve_equals_dense_solve(gpu, oracle, monkeypatch, max_wg, two_launch):
     """vus_ba_band_solve_split / _multi_split: elimination from both ends of the band + dense middle system.  Random
     SPD block bands of many shapes (middle exactly `band` poses or up to 15 more, band not a multiple of the panel,
     systems too short to split -> fallback) against numpy; also with several row groups per workgroup forced."""
     from visual_underwater_slam_amd import _lib
     if max_wg:
         monkeypatch.setenv("VUS_CB_MAX_WG", max_wg)
+    if two_launch:       # the two halves normally take the TRSM + SYRK launch pair per panel; "0": the fused launch
+        monkeypatch.setenv("VUS_BAND_TWO_LAUNCH", two_launch)
     lib = _lib.load()
     rng = np.random.default_rng(11)
     for nP, B in [(33, 9), (97, 8), (131, 37), (200, 90), (260, 17), (64, 20), (57, 1), (500, 60), (40, 30), (20, 3), (333, 41)]:
@@ -357,3 +359,22 @@ def test_two_sided_solve_inside_the_lm_gives_the_one_sided_result(gpu, oracle):
     assert np.allclose(rep1.err_hist, rep2.err_hist, rtol=1e-9)
     assert relerr(poses2.cpu().numpy(), poses1.cpu().numpy()) < 1e-8
     assert relerr(points2.cpu().numpy(), points1.cpu().numpy()) < 1e-7
+
+
+def test_one_sided_band_solve_with_the_two_launch_panel_step(gpu, monkeypatch):
+    """The TRSM + SYRK launch pair (normally used by the two-sided solve) driving a whole one-sided factorisation,
+    including bands narrower than a panel, band 0 and shrinking windows at the end of the matrix."""
+    from visual_underwater_slam_amd import _lib
+    monkeypatch.setenv("VUS_BAND_TWO_LAUNCH", "1")
+    rng = np.random.default_rng(3)
+    for nP, B in [(5, 0), (30, 0), (9, 2), (23, 7), (17, 16), (40, 11), (97, 8), (64, 63), (131, 37), (200, 90)]:
+        A, Sb = _random_band_system(rng, nP, B)
+        for n_rhs in (1, 7):
+            d_S = torch.from_numpy(Sb).cuda()
+            d_st = torch.zeros(1, dtype=torch.int32, device="cuda")
+            rhs = rng.normal(size=(n_rhs, 6 * nP))
+            d_r = torch.from_numpy(rhs).cuda()
+            _lib.call("vus_ba_band_solve_multi", d_S.data_ptr(), nP, B, d_r.data_ptr(), n_rhs, d_st.data_ptr(),
+                      _lib.current_stream_ptr())
+            assert int(d_st.item()) == 0, (nP, B, n_rhs)
+            assert relerr(d_r.cpu().numpy(), np.linalg.solve(A, rhs.T).T) < 1e-10, (nP, B, n_rhs)

@@ -4,7 +4,8 @@ import os
 from ctypes import c_int, c_void_p, c_char_p, c_double
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libvus_hip.so")
+# VUS_HIP_LIB: another build of the same library (A/B timing of kernel variants); never a different implementation
+LIB_PATH = os.environ.get("VUS_HIP_LIB") or os.path.join(_HERE, "csrc", "libvus_hip.so")
 
 _P = c_void_p
 

@@ -468,6 +468,11 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, i
 #define VUS_SR_THREADS 1024
 #endif
 constexpr int SR_ROWS = VUS_SR_ROWS;
+#ifndef VUS_SR_U
+#define VUS_SR_U 3
+#endif
+constexpr int SR_U = VUS_SR_U;           // gathers a lane keeps in flight (schur_rows_kernel)
+constexpr int SR_LD = 19;               // LDS row stride in doubles (18 + 1: see schur_rows_kernel)
 constexpr int SR_THREADS = VUS_SR_THREADS;
 
 __device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int lo, int hi, int key) {
@@ -479,75 +484,171 @@ __device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int lo
   return lo;
 }
 
+// lower_bound over a sorted int array by one wave: 64 probes per step (four dependent loads for 300 000 entries
+// instead of the eighteen of a bisection).  Returns the same value in every lane.
+__device__ __forceinline__ int lower_bound_wave(const int* __restrict__ a, int n, int key, int lane) {
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int len = hi - lo, step = (len + 63) >> 6;
+    const int pos = lo + step * (lane + 1) - 1;
+    const bool in_range = pos < hi;
+    const bool less = in_range && a[in_range ? pos : lo] < key;
+    const int kmax = len / step;                                  // probes inside the range
+    const int c = __popcll(__ballot(less));                       // sorted: the probes below the key come first
+    const int nlo = c == 0 ? lo : lo + step * c;
+    const int nhi = c == kmax ? hi : lo + step * (c + 1) - 1;
+    lo = nlo;
+    hi = nhi;
+  }
+  return lo;
+}
+
+constexpr int SR_MAXB = 512;      // blocks of a row that get scheduled largest first (more: natural order)
+
 __global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure S, const int* __restrict__ pose_ptr,
-                                                                int ps, const double* __restrict__ W,
+                                                                int n_rows, int ps, const double* __restrict__ W,
                                                                 const double* __restrict__ Y,
                                                                 double* __restrict__ Sband) {
-  extern __shared__ double s_y[];          // [rows of the chunk][18]
-  __shared__ int s_b0, s_b1;
-  const int i = blockIdx.x;
+  extern __shared__ double s_y[];          // [rows of the chunk][SR_LD]
+  __shared__ int s_b0, s_b1, s_next;
+  __shared__ int s_cls[16];
+  __shared__ unsigned short s_order[SR_MAXB];
+  // Persistent workgroups, XCD-aware row order.  Block row i gathers W rows of the poses i - band .. i: 16 MB at
+  // configs[2], four times an XCD's L2.  With one workgroup per row in blockIdx order the rows that run together on
+  // an XCD are 8 poses apart and at unrelated points of their walk: every W row comes from the Infinity Cache / HBM
+  // again (PMC: 62 % L2 misses, 9 GB fetched per launch for 0.28 GB of W).  Here every XCD owns a CONTIGUOUS range
+  // of rows and its workgroups (one per CU, blockIdx % 8 = XCD under round-robin dispatch) take rows r, r + 32, ...
+  // of that range: the 32 rows of a round start together and walk the same W segments at the same pace, so one
+  // fetch serves them all (L2 misses 62 % -> 27 %).  Speed only: nothing depends on where a block really runs.
+  const int rows_per_xcd = (n_rows + 7) >> 3;
+  const int wg_per_xcd = (int)(gridDim.x >> 3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid == 0) {
-    s_b0 = lower_bound_i32(S.blk_i, 0, S.n_blocks, i);
-    s_b1 = lower_bound_i32(S.blk_i, 0, S.n_blocks, i + 1);
-  }
-  const int a0 = pose_ptr[i], a1 = pose_ptr[i + 1];
-  __syncthreads();
-  const int b0 = s_b0, b1 = s_b1;
-  if (b0 == b1) return;
   const int res = lane >> 4, sl = lane & 15, rh = res >> 1, ch = res & 1;
   typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));
-  for (int c0 = a0; c0 < a1; c0 += SR_ROWS) {
-    const int c1 = min(c0 + SR_ROWS, a1);
-    if (c0 > a0) __syncthreads();    // the previous chunk has been consumed
-    {
-      const d2_t* src = reinterpret_cast<const d2_t*>(Y + 18 * (size_t)c0);
-      d2_t* dst = reinterpret_cast<d2_t*>(s_y);
-      for (int t = tid; t < 9 * (c1 - c0); t += SR_THREADS) dst[t] = src[t];
+  for (int rr_ = (int)(blockIdx.x >> 3); rr_ < rows_per_xcd; rr_ += wg_per_xcd) {
+    const int i = (int)(blockIdx.x & 7) * rows_per_xcd + rr_;
+    if (i >= n_rows) break;
+    __syncthreads();                 // the previous row's LDS contents have been consumed
+    // the row's blocks [b0, b1): two waves search side by side
+    if (wave < 2) {
+      const int b = lower_bound_wave(S.blk_i, S.n_blocks, i + wave, lane);
+      if (lane == 0) (wave == 0 ? s_b0 : s_b1) = b;
+    }
+    if (tid < 16) s_cls[tid] = 0;
+    const int a0 = pose_ptr[i], a1 = pose_ptr[i + 1];
+    __syncthreads();
+    const int b0 = s_b0, b1 = s_b1;
+    const int nb = b1 - b0;
+    if (nb == 0) continue;
+    // Largest blocks first (counting sort by the bit length of the pair count), handed out dynamically below: the
+    // pair counts of a row's blocks range from a handful to a thousand, and with a static round-robin over the 16
+    // waves the slowest wave carried 1.31x the mean load at configs[2] (largest first: 1.01x).
+    const bool sorted = nb <= SR_MAXB;
+    int my_cls = 0;
+    if (sorted && tid < nb) {
+      const int cnt = S.blk_ptr[b0 + tid + 1] - S.blk_ptr[b0 + tid];
+      my_cls = 15 - min(15, 31 - __clz(cnt | 1));                // 0 = the largest class
+      atomicAdd(&s_cls[my_cls], 1);
     }
     __syncthreads();
-    const bool whole = c0 == a0 && c1 == a1;
-    for (int q = b0 + wave; q < b1; q += SR_THREADS / 64) {
-      const int k = S.blk_k[q];
-      int p0 = S.blk_ptr[q], p1 = S.blk_ptr[q + 1];
-      if (!whole) {   // the pairs whose Y row lies in this chunk
-        p1 = lower_bound_i32(S.pair_a, p0, p1, c1);
-        p0 = lower_bound_i32(S.pair_a, p0, p1, c0);
-      }
-      if (p0 >= p1) continue;
-      double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-      for (int p = p0 + sl; p < p1; p += 16) {
-        const double* Ya = s_y + 18 * (S.pair_a[p] - c0) + 9 * rh;
-        const double* Wb = W + 18 * (size_t)S.pair_b[p] + 9 * ch;
-        double y[9], w[10];
-#pragma unroll
-        for (int h = 0; h < 9; ++h) y[h] = Ya[h];
-#pragma unroll
-        for (int h = 0; h < 4; ++h) {
-          const d2_t wv = *reinterpret_cast<const d2_t*>(Wb + 2 * h);
-          w[2 * h] = wv.x; w[2 * h + 1] = wv.y;
+    if (tid == 0) {
+      int run = 0;
+      for (int c = 0; c < 16; ++c) { const int n = s_cls[c]; s_cls[c] = run; run += n; }
+    }
+    __syncthreads();
+    if (sorted && tid < nb) s_order[atomicAdd(&s_cls[my_cls], 1)] = (unsigned short)tid;
+    for (int c0 = a0; c0 < a1; c0 += SR_ROWS) {
+      const int c1 = min(c0 + SR_ROWS, a1);
+      if (c0 > a0) __syncthreads();    // the previous chunk has been consumed
+      if (tid == 0) s_next = 0;
+      {
+        // rows of 18 doubles land SR_LD = 19 doubles apart: with a stride of 36 dwords the 32 rows one read
+        // instruction touches fall on 16 bank groups and collide (PMC: 69 % of the LDS cycles were bank conflicts)
+        const d2_t* src = reinterpret_cast<const d2_t*>(Y + 18 * (size_t)c0);
+        for (int t = tid; t < 9 * (c1 - c0); t += SR_THREADS) {
+          const d2_t v = src[t];
+          const int row = t / 9, h = t - 9 * row;
+          s_y[SR_LD * row + 2 * h] = v.x;
+          s_y[SR_LD * row + 2 * h + 1] = v.y;
         }
-        w[8] = Wb[8];
+      }
+      __syncthreads();
+      const bool whole = c0 == a0 && c1 == a1;
+      while (true) {
+        int idx = 0;
+        if (lane == 0) idx = atomicAdd(&s_next, 1);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+        if (idx >= nb) break;
+        const int q = b0 + (sorted ? (int)s_order[idx] : idx);
+        const int k = S.blk_k[q];
+        int p0 = S.blk_ptr[q], p1 = S.blk_ptr[q + 1];
+        if (!whole) {   // the pairs whose Y row lies in this chunk
+          p1 = lower_bound_i32(S.pair_a, p0, p1, c1);
+          p0 = lower_bound_i32(S.pair_a, p0, p1, c0);
+        }
+        if (p0 >= p1) continue;
+        double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+        // The walk over a block's pairs is a chain of dependent latencies -- index load, then the gather of the W
+        // row it names, then the products -- so the steps are batched: SR_U gathers of a lane are in flight
+        // together, and the indices of the NEXT batch are requested before the products of this one are formed.
+        int ia[SR_U], ib[SR_U];
+#pragma unroll
+        for (int u = 0; u < SR_U; ++u) {
+          const int p = p0 + sl + 16 * u;
+          ia[u] = p < p1 ? S.pair_a[p] : -1;
+          ib[u] = p < p1 ? S.pair_b[p] : 0;
+        }
+        for (int pb_ = p0 + sl; pb_ < p1; pb_ += 16 * SR_U) {
+          d2_t wv[SR_U][4];
+          double w8[SR_U];
+          int ca[SR_U];
+#pragma unroll
+          for (int u = 0; u < SR_U; ++u) {
+            ca[u] = ia[u];
+            const double* Wb = W + 18 * (size_t)ib[u] + 9 * ch;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) wv[u][h] = *reinterpret_cast<const d2_t*>(Wb + 2 * h);
+            w8[u] = Wb[8];
+          }
+#pragma unroll
+          for (int u = 0; u < SR_U; ++u) {      // indices of the next batch
+            const int p = pb_ + 16 * (SR_U + u);
+            ia[u] = p < p1 ? S.pair_a[p] : -1;
+            ib[u] = p < p1 ? S.pair_b[p] : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < SR_U; ++u) {
+            if (ca[u] < 0) continue;
+            const double* Ya = s_y + SR_LD * (ca[u] - c0) + 9 * rh;
+            const double w[9] = {wv[u][0].x, wv[u][0].y, wv[u][1].x, wv[u][1].y, wv[u][2].x, wv[u][2].y, wv[u][3].x, wv[u][3].y, w8[u]};
+#pragma unroll
+            for (int a2 = 0; a2 < 3; ++a2) {
+              const double y0 = Ya[3 * a2], y1 = Ya[3 * a2 + 1], y2 = Ya[3 * a2 + 2];
+#pragma unroll
+              for (int b2 = 0; b2 < 3; ++b2) acc[a2][b2] += y0 * w[3 * b2] + y1 * w[3 * b2 + 1] + y2 * w[3 * b2 + 2];
+            }
+          }
+        }
+        double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k)) + 6 * (3 * rh) + 3 * ch;
+        // an off-diagonal block of a row that fits one chunk still holds the zeros of the memset: plain store
+        const bool fresh = whole && k != i;
 #pragma unroll
         for (int a2 = 0; a2 < 3; ++a2)
 #pragma unroll
-          for (int b2 = 0; b2 < 3; ++b2)
-            acc[a2][b2] += y[3 * a2] * w[3 * b2] + y[3 * a2 + 1] * w[3 * b2 + 1] + y[3 * a2 + 2] * w[3 * b2 + 2];
+          for (int b2 = 0; b2 < 3; ++b2) {
+            double v = acc[a2][b2];
+            v += dpp_shr_f64<0x111>(v);   // row_shr:1
+            v += dpp_shr_f64<0x112>(v);   // row_shr:2
+            v += dpp_shr_f64<0x114>(v);   // row_shr:4
+            v += dpp_shr_f64<0x118>(v);   // row_shr:8  -> lane 15 of the row holds the sum over its 16 slots
+            if (sl == 15) {
+              if (fresh) blk[6 * a2 + b2] = -v;
+              else blk[6 * a2 + b2] -= v;
+            }
+          }
       }
-      double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k)) + 6 * (3 * rh) + 3 * ch;
-#pragma unroll
-      for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-        for (int b2 = 0; b2 < 3; ++b2) {
-          double v = acc[a2][b2];
-          v += dpp_shr_f64<0x111>(v);   // row_shr:1
-          v += dpp_shr_f64<0x112>(v);   // row_shr:2
-          v += dpp_shr_f64<0x114>(v);   // row_shr:4
-          v += dpp_shr_f64<0x118>(v);   // row_shr:8  -> lane 15 of the row holds the sum over its 16 slots
-          if (sl == 15) blk[6 * a2 + b2] -= v;
-        }
     }
-  }
+  }   // rows of this workgroup
 }
 
 // gs_i = gp_i - sum_{slots of pose i} Y_s gl[point(s)]   (one wave per pose)
@@ -1116,6 +1217,184 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(BandSet S, int ba
   }
 }
 
+// ---- the same panel step as TWO launches (used when two systems share the launches, factor_launches) ----------
+// chol_trsm_update_kernel makes every update tile solve the two row tiles it needs: with ~28 row tiles that is 28x
+// redundant work and 63 KB of LDS per workgroup (two workgroups per CU).  One system per launch hides that behind
+// tile (0,0)'s longer dependent chain; two systems per launch do not (868 workgroups on 512 slots = two rounds).
+// Here the rows are solved ONCE per panel by a small launch (one workgroup per 48-row tile: X = A L_D^-T on the
+// matrix cores, written back in place already transposed for the back-substitution, right-hand sides updated), and
+// the update launch only stages two solved tiles and runs the SYRK: 37 KB of LDS, four workgroups per CU, every
+// tile of both systems resident in one round.
+__global__ __launch_bounds__(256) void chol_trsm_kernel(BandSet S, int band, int k0, int n_rhs) {
+  __shared__ __attribute__((aligned(16))) double Xi[UT * ULD];
+  __shared__ double sL[NB * LDD];
+  __shared__ double sM[3 * 16 * MLD];
+  __shared__ double sInv[NB];
+  __shared__ double s_y[BS_RHS_MAX][NB];
+  const int tid = threadIdx.x;
+  const int sysi = S.count == 2 ? (int)(blockIdx.x & 1) : 0;
+  const int t = S.count == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+  double* __restrict__ Sb = S.s[sysi].Sb;
+  double* __restrict__ yv = S.s[sysi].y;
+  const int n_poses = S.s[sysi].n;
+  const size_t ystride = 6 * (size_t)n_poses;
+  const int pb = min(PB, n_poses - k0);
+  const int nb = 6 * pb;
+  const int i_first = k0 + pb;
+  const int i_last = min(n_poses - 1, k0 + pb - 1 + band);
+  const int p0 = i_first + t * UTP;
+  for (int e = tid; e < NB * n_rhs; e += 256) {      // the panel's solved right-hand sides
+    const int q = e / NB, c = e - NB * q;
+    s_y[q][c] = c < nb ? yv[(size_t)q * ystride + 6 * (size_t)k0 + c] : 0.0;
+  }
+  stage_and_solve(Sb, band, k0, pb, i_last, p0, p0, 1, Xi, Xi, sL, sM, sInv);
+  // X back in place, TRANSPOSED inside each 6x6 block ([column][row]): the SYRK launch and the back-substitution
+  // both read these blocks by column
+  for (int e = tid; e < UTP * PB * 6; e += 256) {
+    const int ii = e / (6 * PB), rem = e - 6 * PB * ii;
+    const int kk = rem / 6, c = rem - 6 * kk;
+    const int i = p0 + ii;
+    if (i <= i_last && kk < pb && kk >= max(0, i - band - k0)) {
+      double* b = blk_ptr(Sb, band, i, k0 + kk) + 6 * c;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) b[r] = Xi[(6 * ii + r) * ULD + 6 * kk + c];
+    }
+  }
+  // y_i -= X_i y_panel: four threads per row, twelve columns each, summed over the 4-lane group
+  {
+    const int row = tid >> 2, part = tid & 3;
+    const int i = p0 + row / 6;
+    for (int q = 0; q < n_rhs; ++q) {
+      double acc = 0.0;
+      if (row < UT) {
+#pragma unroll
+        for (int c2 = 0; c2 < NB / 4; ++c2) acc += Xi[row * ULD + 12 * part + c2] * s_y[q][12 * part + c2];
+      }
+      acc += __shfl_xor(acc, 1);
+      acc += __shfl_xor(acc, 2);
+      if (row < UT && part == 0 && i <= i_last) yv[(size_t)q * ystride + 6 * (size_t)i + (row % 6)] -= acc;
+    }
+  }
+}
+
+// Stage one 48-row tile of SOLVED rows (transposed 6x6 blocks in memory) into LDS, row-major with stride ULD.
+__device__ __forceinline__ void stage_solved_tile(const double* __restrict__ Sb, int band, int k0, int pb, int i_last,
+                                                  int pose0, double* __restrict__ X, int tid, int first, int step) {
+  for (int item = first; item < UTP * PB * 6; item += step) {      // (pose ii, panel pose kk, column c): 6 rows
+    const int ii = item / (6 * PB), rem = item - 6 * PB * ii;
+    const int kk = rem / 6, c = rem - 6 * kk;
+    const int pose = pose0 + ii;
+    const bool have = pose <= i_last && kk < pb && kk >= pose - band - k0;
+    const d2a_t* src = reinterpret_cast<const d2a_t*>(have ? blk_ptr(Sb, band, pose, k0 + kk) + 6 * c : Sb);
+    d2a_t v0 = src[0], v1 = src[have ? 1 : 0], v2 = src[have ? 2 : 0];
+    if (!have) v0 = v1 = v2 = d2a_t{0.0, 0.0};
+    double* dst = X + (6 * ii) * ULD + 6 * kk + c;
+    dst[0] = v0.x; dst[ULD] = v0.y; dst[2 * ULD] = v1.x; dst[3 * ULD] = v1.y; dst[4 * ULD] = v2.x; dst[5 * ULD] = v2.y;
+  }
+}
+
+__global__ __launch_bounds__(256, 4) void chol_syrk_kernel(BandSet S, int band, int k0, int n_rhs, int factor_next) {
+  __shared__ __attribute__((aligned(16))) double Xi[UT * ULD];
+  __shared__ double Xj[UT * ULD];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int sysi = S.count == 2 ? (int)(blockIdx.x & 1) : 0;
+  const int bid = S.count == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
+  double* __restrict__ Sb = S.s[sysi].Sb;
+  double* __restrict__ yv = S.s[sysi].y;
+  int* __restrict__ status = S.s[sysi].status;
+  const int n_poses = S.s[sysi].n;
+  const size_t ystride = 6 * (size_t)n_poses;
+  const int pb = min(PB, n_poses - k0);
+  const int i_first = k0 + pb;
+  const int i_last = min(n_poses - 1, k0 + pb - 1 + band);
+  int ti = (int)((sqrtf(8.0f * (float)bid + 1.0f) - 1.0f) * 0.5f);
+  while ((ti + 1) * (ti + 2) / 2 <= bid) ++ti;
+  while (ti * (ti + 1) / 2 > bid) --ti;
+  const int tj = bid - ti * (ti + 1) / 2;
+  const int pi0 = i_first + ti * UTP, pj0 = i_first + tj * UTP;
+  const double* Xjj = (ti == tj) ? Xi : Xj;
+  const int arow = lane & 15, kq = lane >> 4;
+  // The 48x48 tile in memory: for pose row i the eight blocks (i, pj0 .. pj0+7) are CONTIGUOUS (block (i, j) sits at
+  // slot i - j of row i), 288 doubles starting at block (i, pj0 + 7).  The old values are fetched as 16-byte vectors
+  // (in flight during the staging and the products), the products go through LDS, and the tile leaves as 16-byte
+  // vectors again: the MFMA accumulator layout (one column per lane, rows 4 apart) never touches memory.
+  constexpr int CV = (UTP * 8 * 18 + 255) / 256;       // 16-byte vectors of the tile per thread (1152 / 256 -> 5)
+  d2a_t oldv[CV];
+  unsigned vmask[CV];                                  // bit 0/1: element 0/1 of the vector is part of the band's lower part
+#pragma unroll
+  for (int u = 0; u < CV; ++u) {
+    const int v = tid + 256 * u;
+    const int ii = v / 144, w = v - 144 * ii;
+    const int o = w / 18, e = 2 * (w - 18 * o);
+    const int i = pi0 + ii, j = pj0 + 7 - o;
+    const int rr = e / 6, c = e - 6 * rr;
+    unsigned m = 0;
+    if (v < UTP * 144 && i <= i_last && j <= i) m = (j < i) ? 3u : ((c <= rr ? 1u : 0u) | (c + 1 <= rr ? 2u : 0u));
+    vmask[u] = m;
+    oldv[u] = d2a_t{0.0, 0.0};
+    if (m) oldv[u] = *reinterpret_cast<const d2a_t*>(Sb + 36 * ((long long)i * (band + 1) + (i - j)) + e);
+  }
+  if (ti == tj) {
+    stage_solved_tile(Sb, band, k0, pb, i_last, pi0, Xi, tid, tid, 256);
+  } else {       // two tiles: half of the workgroup each
+    stage_solved_tile(Sb, band, k0, pb, i_last, tid < 128 ? pi0 : pj0, tid < 128 ? Xi : Xj, tid, tid & 127, 128);
+  }
+  __syncthreads();
+  double4_t acc[UQ];
+#pragma unroll
+  for (int q = 0; q < UQ; ++q) {
+    acc[q] = double4_t{0.0, 0.0, 0.0, 0.0};
+    const int t = wave + 4 * q;
+    const int a = t / UMT, b = t - UMT * a;
+    if (t >= UMT * UMT || (ti == tj && b > a)) continue;
+    const double* pa = Xi + (16 * a + arow) * ULD + kq;
+    const double* pbm = Xjj + (16 * b + arow) * ULD + kq;
+#pragma unroll
+    for (int s2 = 0; s2 < NB / 4; ++s2) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s2], pbm[4 * s2], acc[q], 0, 0, 0);
+  }
+  __syncthreads();                     // every wave has read its X fragments: both LDS tiles are free
+  // products -> LDS (Xj), row-major with stride LDD; C/D layout (f64): col = lane & 15, row = (lane >> 4) + 4 * reg
+#pragma unroll
+  for (int q = 0; q < UQ; ++q) {
+    const int t = wave + 4 * q;
+    const int a = t / UMT, b = t - UMT * a;
+    if (t >= UMT * UMT || (ti == tj && b > a)) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) Xj[(16 * a + kq + 4 * r) * LDD + 16 * b + arow] = acc[q][r];
+  }
+  __syncthreads();
+  const bool crit = bid == 0 && factor_next;
+#pragma unroll
+  for (int u = 0; u < CV; ++u) {
+    if (!vmask[u]) continue;
+    const int v = tid + 256 * u;
+    const int ii = v / 144, w = v - 144 * ii;
+    const int o = w / 18, e = 2 * (w - 18 * o);
+    const int i = pi0 + ii, j = pj0 + 7 - o;
+    const int rr = e / 6, c = e - 6 * rr;
+    double* d = Xj + (6 * ii + rr) * LDD + 6 * (7 - o) + c;
+    d2a_t nv = oldv[u];
+    if (vmask[u] & 1u) nv.x -= d[0];
+    if (vmask[u] & 2u) nv.y -= d[1];
+    *reinterpret_cast<d2a_t*>(Sb + 36 * ((long long)i * (band + 1) + (i - j)) + e) = nv;
+    if (crit) { d[0] = nv.x; d[1] = nv.y; }      // tile (0,0): the updated block stays in LDS for the factorisation
+  }
+  if (crit) {
+    // Tile (0,0) is the next panel's diagonal block, complete once this workgroup has stored it: factor it here.
+    // Its right-hand-side rows (already updated by the TRSM launch) go behind the factorisation's ring in Xi.
+    double* s_rhs = Xi + 3 * 64 * 6;   // Xi holds 2352 doubles, the ring of three panels 1152, the rows <= 384
+    for (int e = tid; e < NB * n_rhs; e += 256) {
+      const int q = e / NB, c = e - NB * q;
+      const int i = i_first + c / 6;
+      s_rhs[e] = i <= i_last ? yv[(size_t)q * ystride + 6 * (size_t)i + (c % 6)] : 0.0;
+    }
+    __syncthreads();
+    panel_factor<true>(Sb, n_poses, band, i_first, yv, ystride, n_rhs, status, reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad,
+                       Xj, s_rhs, min(PB, i_last - i_first + 1));
+  }
+}
+
 // x = L^-T y in place (yv), from the last panel to the first.
 //
 // One compute unit cannot stream the factor fast enough (a single CU sustains ~35 GB/s from HBM, the
@@ -1514,13 +1793,21 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
     schur_blocks_kernel<<<cdiv(S->n_blocks, 4), 256, 0, st>>>(*S, ps, W, Y, Sband);
 #else
     static bool lds_set = false;
-    constexpr int lds = SR_ROWS * 18 * (int)sizeof(double);
+    constexpr int lds = SR_ROWS * SR_LD * (int)sizeof(double);
     if (!lds_set) {
       VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(schur_rows_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds));
       lds_set = true;
     }
-    schur_rows_kernel<<<nP, SR_THREADS, lds, st>>>(*S, P->pose_ptr, ps, W, Y, Sband);
+    // one workgroup per CU (it owns 144 KB of LDS), persistent over the rows of its XCD's range
+    static int n_cu = 0;
+    if (!n_cu) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
+    }
+    int wg = 8 * (n_cu / 8);
+    if (wg > 8 * ((nP + 7) / 8)) wg = 8 * ((nP + 7) / 8);
+    schur_rows_kernel<<<wg, SR_THREADS, lds, st>>>(*S, P->pose_ptr, nP, ps, W, Y, Sband);
 #endif
   }
   schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, Y, gl, gp, gs);
@@ -1589,6 +1876,10 @@ int backsolve_max_wg() {
 int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st) {
   const int n = S.s[0].n, c = S.count;
   const bool full = n_elim >= n;
+  // two launches per panel (rows solved once, light update tiles) when two systems share the launches; the fused
+  // launch (every tile solves its rows itself) for a single system.  VUS_BAND_TWO_LAUNCH=0/1 forces either (tests).
+  bool two_launch = c == 2;
+  if (const char* e = getenv("VUS_BAND_TWO_LAUNCH")) two_launch = atoi(e) != 0;
   int k0_prev = -1, tiles_prev = 0;
   for (int k0 = 0; k0 < (full ? n : n_elim); k0 += PB) {
     // panel 0 has a launch of its own; panel p + 1 is factored by tile (0,0) of panel p's update launch
@@ -1601,13 +1892,21 @@ int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream
     const int tiles = rows > 0 ? (rows + UTP - 1) / UTP : 0;
     const int n_update = tiles * (tiles + 1) / 2;
     const int factor_next = (full || k0 + PB < n_elim) ? 1 : 0;
-    // update tiles of this panel + the write-back of the previous panel's solved rows
-    if (n_update + tiles_prev > 0)
+    if (two_launch) {
+      if (tiles > 0) {
+        chol_trsm_kernel<<<c * tiles, 256, 0, st>>>(S, band, k0, n_rhs);
+        chol_syrk_kernel<<<c * n_update, 256, 0, st>>>(S, band, k0, n_rhs, factor_next);
+      }
+    } else if (n_update + tiles_prev > 0) {
+      // update tiles of this panel + the write-back of the previous panel's solved rows
       chol_trsm_update_kernel<<<c * (n_update + tiles_prev), 256, 0, st>>>(S, band, k0, n_update, k0_prev, n_rhs, factor_next);
+    }
+    // no row below this panel (band 0, or a band that ends here): nobody has factored the next panel
+    if (tiles == 0 && factor_next && i_first < n) chol_panel_kernel<<<c, 256, 0, st>>>(S, band, i_first, n_rhs);
     k0_prev = k0;
     tiles_prev = tiles;
   }
-  if (!full && tiles_prev > 0)   // write-back of the last eliminated panel's solved rows
+  if (!two_launch && !full && tiles_prev > 0)   // write-back of the last eliminated panel's solved rows
     chol_trsm_update_kernel<<<c * tiles_prev, 256, 0, st>>>(S, band, n_elim, 0, k0_prev, n_rhs, 0);
   VUS_CHECK_LAUNCH("ba_band_factor");
   return VUS_OK;
