@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the judged profile artefacts on the GPU box (run through gpurun) into gpurun_out/profiles_rNN/.
-# usage: bash tools/collect_profiles.sh r01
+# usage: bash tools/collect_profiles.sh r02
 set -e
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -23,11 +23,11 @@ python3 $ROOT/tools/summarize_pmc.py /tmp/pmc_sq1 /tmp/pmc_sq2 /tmp/pmc_fetch /t
 # 3b. the 8-level pyramid mode (500 frames, 3 passes)
 rm -rf /tmp/prof_py && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_py -- python3 $ROOT/tools/pyramid_profile.py 500 > /dev/null 2>&1 || true
 python3 $ROOT/tools/summarize_stats.py /tmp/prof_py 40 | grep -v "at::native\|rocprim\|rocclr\|compute_cuda" > $OUT/kernel_stats_pyramid_${TAG}.txt || true
-# 4. BA kernels: stats + MFMA counters
+# 4. BA kernels at configs[2]: stats of three linear solves + PMC passes (VALU / LDS / MFMA / L1-L2 / HBM, separate passes)
 rm -rf /tmp/prof_ba && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ba -- python3 $ROOT/tools/ba_profile.py > /dev/null 2>&1 || true
 python3 $ROOT/tools/summarize_stats.py /tmp/prof_ba 40 | grep -v "at::native\|rocprim\|rocclr\|compute_cuda" > $OUT/kernel_stats_ba_${TAG}.txt || true
-rm -rf /tmp/pmc_ba && rocprofv3 --pmc SQ_INSTS_VALU_MFMA_MOPS_F64 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA SQ_WAVE_CYCLES --kernel-trace --output-format csv -d /tmp/pmc_ba -- python3 $ROOT/tools/ba_profile.py 400 10000 400 > /dev/null 2>&1 || true
-python3 $ROOT/tools/summarize_pmc.py /tmp/pmc_ba > $OUT/pmc_ba_${TAG}.txt || true
-# 5. VALU issue-rate micro-benchmark (what bounds the FAST kernel)
+bash $ROOT/tools/pmc_ba.sh $OUT/pmc_ba_${TAG}.txt || true
+# 5. VALU issue-rate micro-benchmark (what bounds the FAST kernel) and the f64 matrix / vector rates (BA rooflines)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $ROOT/tools/ubench/valu_rate.hip -o /tmp/valu_rate 2>/dev/null && /tmp/valu_rate > $OUT/valu_issue_rates_${TAG}.txt || true
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $ROOT/tools/ubench/mfma_f64_rate.hip -o /tmp/mfma_f64_rate 2>/dev/null && /tmp/mfma_f64_rate > $OUT/mfma_f64_rate_${TAG}.txt || true
 ls -la $OUT

@@ -59,6 +59,13 @@ def roofline(prob, stage_ms):
     schur_flops = 2.0 * 108 * npair + 2.0 * 54 * nO              # 6x3 * 3x6 per co-observation pair + Y = W V^-1
     band_bytes = 2.0 * 288 * nN * (B + 1) + 288 * nN * (B + 1)   # factor read + written, read again by the back-substitution
     fl, launches = band_factor_flops(nN, B)
+    # launches of the two-sided solve (csrc/ba.hip split_plan): m poses eliminated from either end in m/8 (TRSM, SYRK)
+    # launch pairs shared by both halves, then the middle system's fused launches, one per 8-pose panel
+    m = ((nN - B) // 2 // PB) * PB if B > 0 else 0
+    split = m >= PB and nN >= 2 * B + 64
+    if split:
+        n_mid = nN - 2 * m
+        launches = 2 * (m // PB) + (n_mid + PB - 1) // PB
     ms = stage_ms
     per_launch_us = 1e3 * ms["band_solve"] / launches           # includes the back-substitution's share
     stages = {
@@ -72,10 +79,12 @@ def roofline(prob, stage_ms):
         "band_solve": {"bound": "mfma", "flops": fl, "achieved": round(fl / (ms["band_solve"] * 1e-3) / 1e12, 2), "peak": F64_PEAK_TFLOPS,
                        "unit": "TFLOP/s", "frac": round(fl / (ms["band_solve"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS, 4),
                        "algorithmic_bytes": band_bytes, "GBps": round(band_bytes / (ms["band_solve"] * 1e-3) / 1e9, 1),
-                       "note": "latency-bound: one launch per 8-pose panel, the launch lasts as long as tile (0,0)'s dependent chain"},
+                       "note": "latency-bound: a chain of dependent panel steps (one per 8 poses; two-sided solve: the two halves "
+                               "share the launches), each as long as tile (0,0)'s dependent chain / one round of update tiles"},
     }
     dom = max(("linearize", "schur", "band_solve"), key=lambda k: ms[k])
-    top = {"kernel": {"band_solve": "chol_trsm_update_kernel", "schur": "schur_rows_kernel", "linearize": "lin_points_kernel"}[dom],
+    top = {"kernel": {"band_solve": "chol_syrk_kernel" if split else "chol_trsm_update_kernel", "schur": "schur_rows_kernel",
+                      "linearize": "lin_points_kernel"}[dom],
            "stage": dom, "bound": stages[dom]["bound"], "achieved": stages[dom]["achieved"], "peak": stages[dom]["peak"],
            "unit": stages[dom]["unit"], "frac": stages[dom]["frac"], "traffic": None}
     if dom == "band_solve":
