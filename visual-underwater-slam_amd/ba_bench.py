@@ -170,12 +170,20 @@ def run(device, n_kf=2000, n_lm=50000, obs_per_kf=1000, with_breakdown=True, rep
             opt = gtsam.LevenbergMarquardtOptimizer(graph, initial, gtsam.LevenbergMarquardtParams())
             res = opt.optimize()
             ts.append(time.perf_counter() - t)
+        import os
+        os.environ["VUS_PROFILE_BOUNDARY"] = "1"        # one more call with synchronising phase marks
+        try:
+            o2 = gtsam.LevenbergMarquardtOptimizer(graph, initial, gtsam.LevenbergMarquardtParams())
+            o2.optimize()
+            phases = getattr(o2.report(), "boundary_ms", None)
+        finally:
+            del os.environ["VUS_PROFILE_BOUNDARY"]
         got = res.pose3_block(X(0) + np.arange(n_kf, dtype=np.int64))
         out["dropin"] = {
             "value": round(statistics.median(ts), 4), "unit": "s",
             "call": "gtsam.LevenbergMarquardtOptimizer(graph, initial, LevenbergMarquardtParams()).optimize() [batch.py:337], "
                     "graph = PriorFactorPose3 + one StereoFactorBlock, Values in array blocks (host numpy in, new Values out)",
-            "lm_loop_s": round(opt.report().seconds, 4),
+            "lm_loop_s": round(opt.report().seconds, 4), "phase_ms": phases,
             "ratio_to_value_cold": round(statistics.median(ts) / (rep.seconds + setup), 2),
             "same_optimum_as_array_path": bool(np.abs(got - poses.cpu().numpy()).max() < 1e-9 * max(1.0, float(np.abs(got).max()))),
         }

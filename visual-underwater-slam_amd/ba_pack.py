@@ -55,26 +55,35 @@ def build_structure(pk):
         z = torch.zeros(0, dtype=torch.int32, device=dev)
         return {"band": 0, "n_blocks": 0, "n_pairs": 0, "blk_ptr": torch.zeros(1, dtype=torch.int32, device=dev),
                 "blk_i": z, "blk_k": z, "pair_a": z, "pair_b": z}
+    # Everything below is sized by the number of co-observation pairs (57 M at configs[2]): 32-bit indices and a
+    # 32-bit sort key wherever they fit halve the bytes every pass moves and the radix passes of the sort.
+    i32 = torch.int32
+    small = n_obs < 2 ** 31 and nP * nP < 2 ** 31
+    idt = i32 if small else torch.int64
     ar = torch.arange(n_obs, device=dev)
     seg_start = pptr[ol]
     counts = ar - seg_start + 1                       # observation a pairs with seg_start..a
     total = int(counts.sum().item())
     if total >= 2 ** 31:
         raise NotImplementedError(f"{total} co-observation pairs exceed the int32 pair index")
-    a_idx = torch.repeat_interleave(ar, counts)
-    excl = torch.cumsum(counts, 0) - counts
-    b_idx = seg_start[a_idx] + (torch.arange(total, device=dev) - excl[a_idx])
-    pi, pk_ = op[a_idx], op[b_idx]                    # pi >= pk_ (poses ascend inside a point)
+    a_idx = torch.repeat_interleave(ar.to(idt), counts)
+    excl = (torch.cumsum(counts, 0) - counts).to(idt)
+    b_idx = seg_start.to(idt)[a_idx] + (torch.arange(total, device=dev, dtype=idt) - excl[a_idx])
+    op_s = op.to(idt)
+    pi, pk_ = op_s[a_idx], op_s[b_idx]                # pi >= pk_ (poses ascend inside a point)
     band = int((pi - pk_).max().item())
     key = pi * nP + pk_
+    del pi, pk_
     key_sorted, order = torch.sort(key, stable=True)
+    del key
     ukey, cnt = torch.unique_consecutive(key_sorted, return_counts=True)
+    del key_sorted
     blk_ptr = torch.zeros(ukey.numel() + 1, dtype=torch.int64, device=dev)
     blk_ptr[1:] = torch.cumsum(cnt, 0)
-    i32 = torch.int32
+    ppos32 = ppos.to(i32)
     return {
         "band": band, "n_blocks": int(ukey.numel()), "n_pairs": total,
         "blk_ptr": blk_ptr.to(i32), "blk_i": torch.div(ukey, nP, rounding_mode="floor").to(i32),
         "blk_k": (ukey % nP).to(i32),
-        "pair_a": ppos[a_idx[order]].to(i32).contiguous(), "pair_b": ppos[b_idx[order]].to(i32).contiguous(),
+        "pair_a": ppos32[a_idx[order]].contiguous(), "pair_b": ppos32[b_idx[order]].contiguous(),
     }

@@ -297,8 +297,19 @@ class LevenbergMarquardtOptimizer:
         from . import Values, Pose3, _ConstantBias
         from .. import _lib
         _lib.require_gpu()                      # no CPU fallback: fail before any work is done
+        import os
+        import time
+        prof = os.environ.get("VUS_PROFILE_BOUNDARY") == "1"     # phase times (synchronising): bench.py's drop-in breakdown
+        marks = [("start", time.perf_counter())]
+
+        def mark(name):
+            if prof:
+                torch.cuda.synchronize()
+                marks.append((name, time.perf_counter()))
         pg = _pack_graph(self._graph, self._initial, self._device)
+        mark("pack_graph_host+upload")
         prob, sv = _build_solver(pg, self._device)
+        mark("structure+workspace")
         aux = pg["aux"] if pg["aux"].keys else None
         nav = pg.get("nav")
         dev = prob.device
@@ -312,6 +323,7 @@ class LevenbergMarquardtOptimizer:
         else:
             poses, points, rep = sv.optimize(torch.from_numpy(pg["poses"]).to(dev), torch.from_numpy(pg["points"]).to(dev),
                                              self._params._to_lm(), aux=aux)
+        mark("lm")
         poses, points = poses.cpu().numpy(), points.cpu().numpy()
         out = Values(self._initial)
         if nav:
@@ -324,6 +336,9 @@ class LevenbergMarquardtOptimizer:
         if aux is not None:
             for k, x in zip(aux.keys, aux.x):
                 out._d[k] = x.copy()
+        mark("read_back")
+        if prof:
+            rep.boundary_ms = {n: round(1e3 * (t - marks[i][1]), 3) for i, (n, t) in enumerate(marks[1:])}
         self._result, self._report = out, rep
         return out
 
