@@ -74,16 +74,22 @@ def build_structure(pk):
     band = int((pi - pk_).max().item())
     key = pi * nP + pk_
     del pi, pk_
+    # the P-order slots of both observations travel through the sort as ONE 64-bit payload: gathering them before
+    # the sort walks ppos almost sequentially (a_idx ascends, b_idx ascends inside every landmark), after it there
+    # is a single random 8-byte gather instead of four 4-byte ones
+    payload = (ppos[a_idx].to(torch.int64) << 32) | ppos[b_idx].to(torch.int64)
+    del a_idx, b_idx
     key_sorted, order = torch.sort(key, stable=True)
     del key
+    payload = payload[order]
+    del order
     ukey, cnt = torch.unique_consecutive(key_sorted, return_counts=True)
     del key_sorted
     blk_ptr = torch.zeros(ukey.numel() + 1, dtype=torch.int64, device=dev)
     blk_ptr[1:] = torch.cumsum(cnt, 0)
-    ppos32 = ppos.to(i32)
     return {
         "band": band, "n_blocks": int(ukey.numel()), "n_pairs": total,
         "blk_ptr": blk_ptr.to(i32), "blk_i": torch.div(ukey, nP, rounding_mode="floor").to(i32),
         "blk_k": (ukey % nP).to(i32),
-        "pair_a": ppos32[a_idx[order]].contiguous(), "pair_b": ppos32[b_idx[order]].contiguous(),
+        "pair_a": (payload >> 32).to(i32).contiguous(), "pair_b": (payload & 0xFFFFFFFF).to(i32).contiguous(),
     }
