@@ -146,7 +146,7 @@ def cpu_baseline_frontend(t0, cores, requested_frames):
     from oracle import oracle as O, engines
     probe = engines.probe()
     out = {"engines": engines.describe(probe)}
-    n_all = requested_frames or max(16, min(64, cores))           # 2 images per frame: >= 2 per thread up to 64 cores
+    n_all = requested_frames or max(32, min(128, 4 * cores))      # 2 images per frame: 8 images per thread
     img_all = synth.stereo_frames(t0, n_all)
     if probe["cv2"] is not None:
         try:

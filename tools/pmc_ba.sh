@@ -13,4 +13,4 @@ pmc tcp TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum
 pmc tcc TCC_HIT_sum TCC_MISS_sum
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
-python3 $ROOT/tools/summarize_pmc.py /tmp/pmcba_sq1 /tmp/pmcba_sq2 /tmp/pmcba_mfma /tmp/pmcba_tcp /tmp/pmcba_tcc /tmp/pmcba_fetch /tmp/pmcba_write > $OUT
+python3 $ROOT/tools/summarize_pmc.py /tmp/pmcba_sq1 /tmp/pmcba_sq2 /tmp/pmcba_mfma /tmp/pmcba_tcp /tmp/pmcba_tcc /tmp/pmcba_fetch /tmp/pmcba_write --launch-traffic-json $(dirname $OUT)/traffic_ba.json > $OUT

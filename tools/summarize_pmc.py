@@ -44,3 +44,20 @@ if "--traffic-json" in sys.argv:
                             "tools/ubench/valu_rate.hip (profiles/valu_issue_rates_*.txt): v_min3/v_max3_i32, v_alignbyte, v_bfe, "
                             "SDWA and v_dot4 issue at 1.7-1.85 ns, plain add/xor/and at 1.0-1.09 ns"},
               open(path, "w"), indent=1)
+
+# optional: --launch-traffic-json <path>  -> HBM-side bytes per LAUNCH per kernel (BA kernels: one launch = one unit)
+if "--launch-traffic-json" in sys.argv:
+    import json
+    path = sys.argv[sys.argv.index("--launch-traffic-json") + 1]
+    res = {}
+    for k, cs in out.items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            kk = k.split("<")[0]
+            f = sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"]) * 1024
+            w = sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"]) * 1024
+            res[kk] = {"fetch_raw": f, "fetch": 2.0 * f, "write": w, "launches_sampled": len(cs["FETCH_SIZE"])}
+    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), tools/ba_profile.py at configs[2]",
+               "note": "bytes per launch; fetch = 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads, "
+                       "MI355X_MICROARCH.md; plausibility: chol_syrk must read two 7.3 MB windows + the solved rows once per XCD "
+                       "= ~22 MB and write 14.5 MB per launch), write = WRITE_SIZE",
+               "bytes_per_launch": res}, open(path, "w"), indent=1)

@@ -87,6 +87,14 @@ def roofline(prob, stage_ms):
                       "linearize": "lin_points_kernel"}[dom],
            "stage": dom, "bound": stages[dom]["bound"], "achieved": stages[dom]["achieved"], "peak": stages[dom]["peak"],
            "unit": stages[dom]["unit"], "frac": stages[dom]["frac"], "traffic": None}
+    try:       # HBM-side bytes per launch of the dominant kernel from the committed PMC summary (profiles/traffic_ba.json)
+        import json, os
+        tj = json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic_ba.json")))
+        t = tj["bytes_per_launch"][top["kernel"]]
+        top["traffic"] = int(t["fetch"] + t["write"])
+        top["traffic_note"] = "FETCH_SIZE x 2 + WRITE_SIZE per launch of " + top["kernel"] + " (separate rocprofv3 --pmc passes)"
+    except Exception:
+        pass
     if dom == "band_solve":
         top.update({"launches_per_solve": launches, "avg_launch_us": round(per_launch_us, 2),
                     "flops_per_launch": round(fl / launches), "note": "f64 flops of the band Cholesky per launch / "
