@@ -387,8 +387,6 @@ __global__ void schur_init_kernel(int n_poses, int band, int ps, double lambda, 
   Sband[36 * (size_t)(ps * i) * (band + 1) + e] = Hpp[t] + ((e % 7 == 0) ? lambda : 0.0);
 }
 
-// One wave per non-zero block (i,k): S_ik -= sum_pairs Y_a W_b^T.
-// 60 lanes = 5 pair slices x 12 strips (row r, three columns); slices are summed in a fixed order.
 // lane L receives the value of lane L - n of its 16-lane row (0 for the first n lanes): DPP row_shr:n
 template <int CTRL>
 __device__ __forceinline__ double dpp_shr_f64(double v) {
@@ -397,70 +395,19 @@ __device__ __forceinline__ double dpp_shr_f64(double v) {
   return __hiloint2double(hi, lo);
 }
 
-__global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, int ps, const double* __restrict__ W,
-                                                           const double* __restrict__ Y,
-                                                           double* __restrict__ Sband) {
-  const int lane = threadIdx.x & 63;
-  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (q >= S.n_blocks) return;
-  const int i = S.blk_i[q], k = S.blk_k[q];
-  const int p0 = S.blk_ptr[q], p1 = S.blk_ptr[q + 1];
-  // Four lanes per pair: lane (rh, ch) loads rows 3rh..3rh+2 of Y_a and 3ch..3ch+2 of W_b (9 contiguous
-  // doubles each) and accumulates the 3x3 sub-block -- 576 B requested from the L1 per pair instead of
-  // 1152 B with 12 lanes per pair (3.2 -> 2.0 ms at configs[2]).  Fewer lanes per pair do not help further
-  // (2 lanes: 2.07 ms, 1 lane: 2.6 ms, measured): 57.5 M pairs x 288 B of unique rows = 16.5 GB cross the L2 -> L1
-  // path in those 2 ms, about what that path sustains for a gather.
-  const int sl = lane >> 2, rh = (lane >> 1) & 1, ch = lane & 1;
-  typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));   // 16-byte loads from 8-byte aligned rows
-  double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (int p = p0 + sl; p < p1; p += 16) {
-    const double* Ya = Y + 18 * (size_t)S.pair_a[p] + 9 * rh;
-    const double* Wb = W + 18 * (size_t)S.pair_b[p] + 9 * ch;
-    double y[10], w[10];
-#pragma unroll
-    for (int h = 0; h < 4; ++h) {
-      const d2_t yv = *reinterpret_cast<const d2_t*>(Ya + 2 * h), wv = *reinterpret_cast<const d2_t*>(Wb + 2 * h);
-      y[2 * h] = yv.x; y[2 * h + 1] = yv.y;
-      w[2 * h] = wv.x; w[2 * h + 1] = wv.y;
-    }
-    y[8] = Ya[8];
-    w[8] = Wb[8];
-#pragma unroll
-    for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-      for (int b2 = 0; b2 < 3; ++b2)
-        acc[a2][b2] += y[3 * a2] * w[3 * b2] + y[3 * a2 + 1] * w[3 * b2 + 1] + y[3 * a2 + 2] * w[3 * b2 + 2];
-  }
-  // sum over the 16 pair slots: inside a 16-lane row with DPP shifts (lanes 12..15 end up with the row
-  // totals of the four (rh, ch) residues), across the four rows through a wave-private LDS patch
-  __shared__ double s_red[4][4][4][9];   // [wave][row][residue][value]
-  const int wv = threadIdx.x >> 6, rowi = (lane >> 4) & 3;
-#pragma unroll
-  for (int a2 = 0; a2 < 3; ++a2)
-#pragma unroll
-    for (int b2 = 0; b2 < 3; ++b2) {
-      double v = acc[a2][b2];
-      v += dpp_shr_f64<0x114>(v);   // row_shr:4
-      v += dpp_shr_f64<0x118>(v);   // row_shr:8
-      if ((lane & 15) >= 12) s_red[wv][rowi][lane & 3][3 * a2 + b2] = v;
-    }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the wave's own LDS writes have landed
-  if (lane < 36) {
-    const int res = lane / 9, e = lane - 9 * res;     // residue (rh, ch) = (res >> 1, res & 1), element (a2, b2)
-    const double t = s_red[wv][0][res][e] + s_red[wv][1][res][e] + s_red[wv][2][res][e] + s_red[wv][3][res][e];
-    const int a2 = e / 3, b2 = e - 3 * a2;
-    double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k));
-    blk[6 * (3 * (res >> 1) + a2) + 3 * (res & 1) + b2] -= t;
-  }
+// lanes of rows 1 and 3 receive lane 15 of the row before them (0 elsewhere): DPP row_bcast:15
+__device__ __forceinline__ double dpp_bcast15_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xa, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xa, 0xf, true);
+  return __hiloint2double(hi, lo);
 }
 
-// Row-resident variant of the block accumulation: one workgroup per pose i keeps that pose's Y rows (its
-// P-order segment, <= SR_ROWS x 144 B per chunk) in LDS while its waves walk the blocks (i, k) of the row,
-// so only the W rows travel L2 -> L1 per pair (144 B instead of 288 B).  Lane = 16 * (rh, ch) + pair slot: a
-// 16-lane DPP row holds one 3x3 sub-block position, and the sum over the 16 slots is four DPP row shifts
-// with no cross-row step.  Rows longer than SR_ROWS are processed in chunks (pair_a ascends inside a block,
-// so a chunk's pairs are a sub-range found by bisection).  Deterministic, no atomics.
+// Row-resident block accumulation: a workgroup keeps the Y rows of pose i (its P-order segment, <= SR_ROWS rows per
+// chunk) in LDS while its waves walk the blocks (i, k) of the row, so only the W rows travel L2 -> L1 per pair
+// (144 B instead of 288 B).  Lane = 32 * ch + pair slot: a lane owns the 6x3 half block of columns 3ch .. 3ch+2 and
+// the sum over the 32 slots is four DPP row shifts plus one row broadcast (fixed order: deterministic, no atomics).
+// Rows longer than SR_ROWS are processed in chunks (pair_a ascends inside a block, so a chunk's pairs are a
+// sub-range found by bisection).
 #ifndef VUS_SR_ROWS
 #define VUS_SR_ROWS 1000
 #endif
@@ -469,7 +416,7 @@ __global__ __launch_bounds__(256) void schur_blocks_kernel(vus_ba_structure S, i
 #endif
 constexpr int SR_ROWS = VUS_SR_ROWS;
 #ifndef VUS_SR_U
-#define VUS_SR_U 3
+#define VUS_SR_U 1
 #endif
 constexpr int SR_U = VUS_SR_U;           // gathers a lane keeps in flight (schur_rows_kernel)
 constexpr int SR_LD = 19;               // LDS row stride in doubles (18 + 1: see schur_rows_kernel)
@@ -523,7 +470,6 @@ __global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure
   const int rows_per_xcd = (n_rows + 7) >> 3;
   const int wg_per_xcd = (int)(gridDim.x >> 3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int res = lane >> 4, sl = lane & 15, rh = res >> 1, ch = res & 1;
   typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));
   for (int rr_ = (int)(blockIdx.x >> 3); rr_ < rows_per_xcd; rr_ += wg_per_xcd) {
     const int i = (int)(blockIdx.x & 7) * rows_per_xcd + rr_;
@@ -587,61 +533,67 @@ __global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure
           p0 = lower_bound_i32(S.pair_a, p0, p1, c0);
         }
         if (p0 >= p1) continue;
-        double acc[3][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-        // The walk over a block's pairs is a chain of dependent latencies -- index load, then the gather of the W
-        // row it names, then the products -- so the steps are batched: SR_U gathers of a lane are in flight
-        // together, and the indices of the NEXT batch are requested before the products of this one are formed.
+        // Two lanes per pair: lane = 32 * ch + slot, each lane owns the 6x3 half block of columns 3ch .. 3ch+2 and
+        // the wave takes 32 pairs per step.  The W-row gather costs per INSTRUCTION, not per byte (A/B builds,
+        // r02_summary: two loads per lane instead of five: 1.55 -> 1.05 ms); with four lanes per pair the quadrants
+        // (rh = 0, 1) of a pair fetched the same 72 bytes twice, i.e. ten load instructions per 32 pairs for five
+        // instructions' worth of distinct bytes.
+        const int sl2 = lane & 31, ch2 = lane >> 5;
+        double acc[6][3];
+#pragma unroll
+        for (int a2 = 0; a2 < 6; ++a2) acc[a2][0] = acc[a2][1] = acc[a2][2] = 0.0;
         int ia[SR_U], ib[SR_U];
 #pragma unroll
         for (int u = 0; u < SR_U; ++u) {
-          const int p = p0 + sl + 16 * u;
+          const int p = p0 + sl2 + 32 * u;
           ia[u] = p < p1 ? S.pair_a[p] : -1;
           ib[u] = p < p1 ? S.pair_b[p] : 0;
         }
-        for (int pb_ = p0 + sl; pb_ < p1; pb_ += 16 * SR_U) {
+        for (int pb_ = p0 + sl2; pb_ < p1; pb_ += 32 * SR_U) {
           d2_t wv[SR_U][4];
           double w8[SR_U];
           int ca[SR_U];
 #pragma unroll
           for (int u = 0; u < SR_U; ++u) {
             ca[u] = ia[u];
-            const double* Wb = W + 18 * (size_t)ib[u] + 9 * ch;
+            const double* Wb = W + 18 * (size_t)ib[u] + 9 * ch2;
 #pragma unroll
             for (int h = 0; h < 4; ++h) wv[u][h] = *reinterpret_cast<const d2_t*>(Wb + 2 * h);
             w8[u] = Wb[8];
           }
 #pragma unroll
           for (int u = 0; u < SR_U; ++u) {      // indices of the next batch
-            const int p = pb_ + 16 * (SR_U + u);
+            const int p = pb_ + 32 * (SR_U + u);
             ia[u] = p < p1 ? S.pair_a[p] : -1;
             ib[u] = p < p1 ? S.pair_b[p] : 0;
           }
 #pragma unroll
           for (int u = 0; u < SR_U; ++u) {
             if (ca[u] < 0) continue;
-            const double* Ya = s_y + SR_LD * (ca[u] - c0) + 9 * rh;
+            const double* Ya = s_y + SR_LD * (ca[u] - c0);
             const double w[9] = {wv[u][0].x, wv[u][0].y, wv[u][1].x, wv[u][1].y, wv[u][2].x, wv[u][2].y, wv[u][3].x, wv[u][3].y, w8[u]};
 #pragma unroll
-            for (int a2 = 0; a2 < 3; ++a2) {
+            for (int a2 = 0; a2 < 6; ++a2) {
               const double y0 = Ya[3 * a2], y1 = Ya[3 * a2 + 1], y2 = Ya[3 * a2 + 2];
 #pragma unroll
               for (int b2 = 0; b2 < 3; ++b2) acc[a2][b2] += y0 * w[3 * b2] + y1 * w[3 * b2 + 1] + y2 * w[3 * b2 + 2];
             }
           }
         }
-        double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k)) + 6 * (3 * rh) + 3 * ch;
+        double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k)) + 3 * ch2;
         // an off-diagonal block of a row that fits one chunk still holds the zeros of the memset: plain store
         const bool fresh = whole && k != i;
 #pragma unroll
-        for (int a2 = 0; a2 < 3; ++a2)
+        for (int a2 = 0; a2 < 6; ++a2)
 #pragma unroll
           for (int b2 = 0; b2 < 3; ++b2) {
             double v = acc[a2][b2];
             v += dpp_shr_f64<0x111>(v);   // row_shr:1
             v += dpp_shr_f64<0x112>(v);   // row_shr:2
             v += dpp_shr_f64<0x114>(v);   // row_shr:4
-            v += dpp_shr_f64<0x118>(v);   // row_shr:8  -> lane 15 of the row holds the sum over its 16 slots
-            if (sl == 15) {
+            v += dpp_shr_f64<0x118>(v);   // row_shr:8  -> lane 15 of every 16-lane row holds that row's sum
+            v += dpp_bcast15_f64(v);      // row_bcast:15 -> lane 31 (63) = slots 0..31 of ch = 0 (1), in a fixed order
+            if (sl2 == 31) {
               if (fresh) blk[6 * a2 + b2] = -v;
               else blk[6 * a2 + b2] -= v;
             }
@@ -1789,9 +1741,6 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
   if (nO > 0) ymul_kernel<<<cdiv(nO, 256), 256, 0, st>>>(*P, W, Vinv, Y);
   schur_init_kernel<<<cdiv(36ll * nP, 256), 256, 0, st>>>(nP, S->band, ps, lambda, Hpp, Sband);
   if (S->n_blocks > 0) {
-#ifdef VUS_SCHUR_BLOCKS
-    schur_blocks_kernel<<<cdiv(S->n_blocks, 4), 256, 0, st>>>(*S, ps, W, Y, Sband);
-#else
     static bool lds_set = false;
     constexpr int lds = SR_ROWS * SR_LD * (int)sizeof(double);
     if (!lds_set) {
@@ -1808,7 +1757,6 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
     int wg = 8 * (n_cu / 8);
     if (wg > 8 * ((nP + 7) / 8)) wg = 8 * ((nP + 7) / 8);
     schur_rows_kernel<<<wg, SR_THREADS, lds, st>>>(*S, P->pose_ptr, nP, ps, W, Y, Sband);
-#endif
   }
   schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, Y, gl, gp, gs);
   VUS_CHECK_LAUNCH("ba_schur");
