@@ -257,7 +257,9 @@ int vus_ba_add_diag(double* Sband, int n_poses, int band, double value, void* st
  * the solver's own layout: the 6x6 blocks left of the 8-node diagonal panels hold their transposes.
  * status[0] = 0 ok, k+1 = non-positive pivot met in scalar column k (dp is then undefined), -1 = the
  * cooperative back-substitution gave up waiting (never observed; the waits are bounded so that a scheduling
- * anomaly cannot hang the GPU).  The sweep's flags live in the unused slots of block row 0 of Sband. */
+ * anomaly cannot hang the GPU).  The sweep's flags live in the unused slots of block row 0 of Sband.
+ * The back-substitution adds its partial products with f64 atomics: two solves of the same system agree to ~1e-13
+ * relative, not bitwise. */
 int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, double* dp,
                       int* status, void* stream);
 
@@ -281,7 +283,8 @@ int vus_ba_band_solve_multi_split(double* Sband, int n_nodes, int band, double* 
 
 /* ---- navigation factors on the camera side (graphs with vus_nav_factors, pose_stride = 2) ----
  * vus_nav_linearize: residuals/Jacobians of every ImuFactor / DVL factor / velocity prior at
- * (poses, vels, bias), accumulated (in a fixed order) into
+ * (poses, vels, bias), accumulated (camera-side blocks with f64 atomics -- at most four addends per block, so two runs
+ * agree to ~1e-16 relative, not bitwise; the bias block and gradient in a fixed order) into
  *   Snav [n_nodes,4,36]  blocks (node, node-s), s = 0..3   (undamped)
  *   Scb  [n_nodes,36]    coupling of every node with the shared bias (node rows x bias columns)
  *   Sbb  [36], gnav [6*n_nodes], gb [6]

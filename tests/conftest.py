@@ -26,3 +26,14 @@ def gpu():
     if not torch.cuda.is_available():
         pytest.skip("no GPU visible")
     return torch.device("cuda:0")
+
+
+def same_lm_trajectory(iterations, outer, tries, status, err_hist, orep):
+    """The GPU LM walked the oracle's trajectory: same linearisations, trials and status.  The number of ACCEPTED steps
+    may differ by one only through a round-off tie at the optimum: the last trial changes the error in the 15th digit
+    and `cost_change > 0` is decided by summation order (the cooperative back-substitution sums with f64 atomics)."""
+    assert (outer, tries, status) == (orep["outer"], orep["tries"], orep["status"])
+    if iterations != orep["iterations"]:
+        h = list(err_hist)
+        assert abs(iterations - orep["iterations"]) == 1 and len(h) >= 2 and abs(h[-1] - h[-2]) <= 1e-12 * abs(h[-1]), \
+            (iterations, orep["iterations"], h[-3:])

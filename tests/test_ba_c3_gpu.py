@@ -151,5 +151,5 @@ def test_c3_through_the_gtsam_shaped_boundary(c3):
     poses, points, rep = sv.optimize(torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda())
     got = res.pose3_block(X(0) + np.arange(N_KF, dtype=np.int64))
     assert relerr(got, poses.cpu().numpy()) < 1e-9
-    assert opt.iterations() == rep.iterations and np.isclose(opt.error(), rep.final_error, rtol=1e-9)
+    assert abs(opt.iterations() - rep.iterations) <= 1 and np.isclose(opt.error(), rep.final_error, rtol=1e-9)
     assert np.allclose(res.atPose3(X(1234)).flat12(), got[1234])             # object read-back, batch.py:57-68
