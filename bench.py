@@ -183,12 +183,12 @@ def cpu_baseline_frontend(t0, cores, requested_frames):
     run(min(n_all, 4), cores)                                       # warm-up
     t_all = statistics.median(run(n_all, cores) for _ in range(5))
     n_one = 2
-    t_one = statistics.median(run(n_one, 1) for _ in range(3))
+    t_one = statistics.median(run(n_one, 1) for _ in range(5))
     out.update({"value": round(n_all / t_all, 3), "unit": "frames/s", "cores": cores, "kind": "port",
                 "value_1thread": round(n_one / t_one, 3),
                 "sample": f"C port (gcc -O3 -march=native, OpenMP over the {2 * n_all} images): first {n_all} stereo frames of "
                           f"the same stream, {cores} threads, median of 5 = {t_all:.2f} s; 1 thread: first {n_one} frames, "
-                          f"median of 3 = {t_one:.2f} s.  Not OpenCV: cv2 is absent on this machine"})
+                          f"median of 5 = {t_one:.2f} s.  Not OpenCV: cv2 is absent on this machine"})
     return out
 
 
@@ -234,17 +234,17 @@ def cpu_baseline_ba(seq, cores, gpu_seconds):
             calib[bt] = time.perf_counter() - t
         best_bt = min(calib, key=calib.get)
         del probe_port
-        for _ in range(3):
+        for _ in range(5):
             _, _, rep = ba_port.BAPort(P, st, native=True, blas_threads=best_bt).optimize(seq["poses_init"], seq["points_init"], max_seconds=60)
             runs.append(rep)
-    rep = sorted(runs, key=lambda r: r["seconds"])[1]
+    rep = sorted(runs, key=lambda r: r["seconds"])[2]
     with ba_port.set_threads(1):
         _, _, rep1 = ba_port.BAPort(P, st, native=True).optimize(seq["poses_init"], seq["points_init"], max_seconds=30)
     out.update({
         "value": round(rep["seconds"], 3), "unit": "s", "cores": cores, "kind": "port",
         "sample": f"full LM at configs[2] ({n_kf} keyframes / {nL} landmarks / {len(seq['obs_pose'])} stereo factors): CPU port = "
                   f"OpenMP kernels (gcc -O3 -march=native, {cores} threads) + LAPACK dpbtrf/dpbtrs (scipy OpenBLAS, {best_bt} threads: "
-                  f"the fastest of {{{', '.join(f'{k}: {v:.2f} s' for k, v in calib.items())}}} per factorisation), median of 3, "
+                  f"the fastest of {{{', '.join(f'{k}: {v:.2f} s' for k, v in calib.items())}}} per factorisation), median of 5, "
                   f"{rep['tries']} linear solves" + (" (stopped at the 60 s bound)" if rep["truncated"] else "") +
                   ".  Not GTSAM: gtsam is absent on this machine",
         "s_per_linear_solve": round(rep["seconds"] / max(rep["tries"], 1), 3),
