@@ -288,8 +288,8 @@ def _random_band_system(rng, nP, B):
     return A, Sb
 
 
-@pytest.mark.parametrize("max_wg,two_launch", [(None, None), ("3", None), (None, "0")])
-def test_two_sided_band_solve_equals_dense_solve(gpu, oracle, monkeypatch, max_wg, two_launch):
+@pytest.mark.parametrize("max_wg,two_launch,mode", [(None, None, None), ("3", None, None), (None, "0", None), (None, None, "1")])
+def test_two_sided_band_solve_equals_dense_solve(gpu, oracle, monkeypatch, max_wg, two_launch, mode):
     """vus_ba_band_solve_split / _multi_split: elimination from both ends of the band + dense middle system.  Random
     SPD block bands of many shapes (middle exactly `band` poses or up to 15 more, band not a multiple of the panel,
     systems too short to split -> fallback) against numpy; also with several row groups per workgroup forced."""
@@ -298,6 +298,8 @@ def test_two_sided_band_solve_equals_dense_solve(gpu, oracle, monkeypatch, max_w
         monkeypatch.setenv("VUS_CB_MAX_WG", max_wg)
     if two_launch:       # the two halves normally take the TRSM + SYRK launch pair per panel; "0": the fused launch
         monkeypatch.setenv("VUS_BAND_TWO_LAUNCH", two_launch)
+    if mode:             # default: the halves on two streams; "1": both halves share every launch of one stream
+        monkeypatch.setenv("VUS_BAND_MODE", mode)
     lib = _lib.load()
     rng = np.random.default_rng(11)
     for nP, B in [(33, 9), (97, 8), (131, 37), (200, 90), (260, 17), (64, 20), (57, 1), (500, 60), (40, 30), (20, 3), (333, 41)]:

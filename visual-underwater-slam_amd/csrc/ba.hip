@@ -1821,17 +1821,31 @@ int backsolve_max_wg() {
 // eliminated (n_elim == S.s[0].n: the whole matrix; smaller, a multiple of PB: a PARTIAL factorisation that leaves the
 // Schur complement of the eliminated poses in the trailing window and the forward-substituted right-hand sides
 // in y).  The forward substitution rides along.
-int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st) {
-  const int n = S.s[0].n, c = S.count;
+int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st, hipStream_t st2 = nullptr) {
+  const int n = S.s[0].n;
   const bool full = n_elim >= n;
-  // two launches per panel (rows solved once, light update tiles) when two systems share the launches; the fused
-  // launch (every tile solves its rows itself) for a single system.  VUS_BAND_TWO_LAUNCH=0/1 forces either (tests).
-  bool two_launch = c == 2;
-  if (const char* e = getenv("VUS_BAND_TWO_LAUNCH")) two_launch = atoi(e) != 0;
+  // Three ways to issue a panel step (VUS_BAND_MODE = 0 / 1 / 2 forces one; tests and A/B timing):
+  //  0  fused launch: every update tile solves its rows itself -- one system;
+  //  1  TRSM launch + SYRK launch shared by both systems (rows solved once, light update tiles, one round);
+  //  2  the two systems on two STREAMS, a (TRSM, SYRK) launch pair each per panel, issued alternately: the halves of
+  //     the two-sided solve are independent chains, so one half's small TRSM launch runs beside the other's update
+  //     (band solve at configs[2]: mode 0 4.64 ms, mode 1 4.31 ms, mode 2 4.11 ms; the fused launch per half on two
+  //     streams was measured too: 4.15 ms).
+  int mode = S.count == 2 ? (st2 ? 2 : 1) : 0;
+  if (const char* e = getenv("VUS_BAND_TWO_LAUNCH")) mode = atoi(e) != 0 ? (S.count == 2 && st2 && mode == 2 ? 2 : 1) : 0;
+  if (const char* e = getenv("VUS_BAND_MODE")) { const int m = atoi(e); if (m == 0 || m == 1 || (m == 2 && S.count == 2 && st2)) mode = m; }
+  BandSet one[2];
+  hipStream_t sts[2] = {st, st2};
+  int n_sets = 1;
+  const bool fused = mode == 0;
+  if (mode == 2) {
+    n_sets = 2;
+    for (int q = 0; q < 2; ++q) { one[q].count = 1; one[q].s[0] = S.s[q]; one[q].s[1] = S.s[q]; }
+  } else {
+    one[0] = S;
+  }
   int k0_prev = -1, tiles_prev = 0;
   for (int k0 = 0; k0 < (full ? n : n_elim); k0 += PB) {
-    // panel 0 has a launch of its own; panel p + 1 is factored by tile (0,0) of panel p's update launch
-    if (k0 == 0) chol_panel_kernel<<<c, 256, 0, st>>>(S, band, k0, n_rhs);
     const int pb = n - k0 < PB ? n - k0 : PB;
     const int i_first = k0 + pb;
     int i_last = k0 + pb - 1 + band;
@@ -1840,24 +1854,54 @@ int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream
     const int tiles = rows > 0 ? (rows + UTP - 1) / UTP : 0;
     const int n_update = tiles * (tiles + 1) / 2;
     const int factor_next = (full || k0 + PB < n_elim) ? 1 : 0;
-    if (two_launch) {
-      if (tiles > 0) {
-        chol_trsm_kernel<<<c * tiles, 256, 0, st>>>(S, band, k0, n_rhs);
-        chol_syrk_kernel<<<c * n_update, 256, 0, st>>>(S, band, k0, n_rhs, factor_next);
+    for (int q = 0; q < n_sets; ++q) {
+      const BandSet& B = one[q];
+      const int c = B.count;
+      hipStream_t s_ = sts[q];
+      // panel 0 has a launch of its own; panel p + 1 is factored by tile (0,0) of panel p's update launch
+      if (k0 == 0) chol_panel_kernel<<<c, 256, 0, s_>>>(B, band, k0, n_rhs);
+      if (!fused) {
+        if (tiles > 0) {
+          chol_trsm_kernel<<<c * tiles, 256, 0, s_>>>(B, band, k0, n_rhs);
+          chol_syrk_kernel<<<c * n_update, 256, 0, s_>>>(B, band, k0, n_rhs, factor_next);
+        }
+      } else if (n_update + tiles_prev > 0) {
+        // update tiles of this panel + the write-back of the previous panel's solved rows
+        chol_trsm_update_kernel<<<c * (n_update + tiles_prev), 256, 0, s_>>>(B, band, k0, n_update, k0_prev, n_rhs, factor_next);
       }
-    } else if (n_update + tiles_prev > 0) {
-      // update tiles of this panel + the write-back of the previous panel's solved rows
-      chol_trsm_update_kernel<<<c * (n_update + tiles_prev), 256, 0, st>>>(S, band, k0, n_update, k0_prev, n_rhs, factor_next);
+      // no row below this panel (band 0, or a band that ends here): nobody has factored the next panel
+      if (tiles == 0 && factor_next && i_first < n) chol_panel_kernel<<<c, 256, 0, s_>>>(B, band, i_first, n_rhs);
     }
-    // no row below this panel (band 0, or a band that ends here): nobody has factored the next panel
-    if (tiles == 0 && factor_next && i_first < n) chol_panel_kernel<<<c, 256, 0, st>>>(S, band, i_first, n_rhs);
     k0_prev = k0;
     tiles_prev = tiles;
   }
-  if (!two_launch && !full && tiles_prev > 0)   // write-back of the last eliminated panel's solved rows
-    chol_trsm_update_kernel<<<c * tiles_prev, 256, 0, st>>>(S, band, n_elim, 0, k0_prev, n_rhs, 0);
+  if (fused && !full && tiles_prev > 0)   // write-back of the last eliminated panel's solved rows
+    for (int q = 0; q < n_sets; ++q)
+      chol_trsm_update_kernel<<<one[q].count * tiles_prev, 256, 0, sts[q]>>>(one[q], band, n_elim, 0, k0_prev, n_rhs, 0);
   VUS_CHECK_LAUNCH("ba_band_factor");
   return VUS_OK;
+}
+
+// A second stream and two events per device for the two-sided solve's fork / join (created once, never destroyed).
+struct SplitAux {
+  hipStream_t s2 = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  bool ok = false;
+};
+SplitAux* split_aux() {
+  static std::mutex mu;
+  static SplitAux aux[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  std::lock_guard<std::mutex> lock(mu);
+  SplitAux& a = aux[dev];
+  if (!a.ok) {
+    if (hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    a.ok = true;
+  }
+  return &a;
 }
 
 // Cooperative back-substitution x = L^-T y of every system of S (n_solve > 0: of its leading n_solve poses only).
@@ -2062,7 +2106,21 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
   S.count = 2;
   S.s[0] = BandSys{Sband, yT, status, nullptr, p.nT};
   S.s[1] = BandSys{Rb, yR, st_R, nullptr, p.nT};
-  if (int rc = factor_launches(S, band, p.m, n_rhs, st)) return rc;
+  {
+    // the halves are independent chains until the middle system: the pose-reversed one runs on a second stream
+    SplitAux* aux = nullptr;
+    const char* e = getenv("VUS_BAND_MODE");
+    if (!e || atoi(e) == 2) aux = split_aux();
+    if (aux) {
+      VUS_CHECK_HIP(hipEventRecord(aux->fork, st));
+      VUS_CHECK_HIP(hipStreamWaitEvent(aux->s2, aux->fork, 0));
+    }
+    if (int rc = factor_launches(S, band, p.m, n_rhs, st, aux ? aux->s2 : nullptr)) return rc;
+    if (aux) {
+      VUS_CHECK_HIP(hipEventRecord(aux->join, aux->s2));
+      VUS_CHECK_HIP(hipStreamWaitEvent(st, aux->join, 0));
+    }
+  }
   const size_t nM = 36 * (size_t)p.n_mid * (p.bm + 1);
   split_mid_kernel<<<cdiv((long long)nM, 256), 256, 0, st>>>(Sband, y, p, Rb, yT, yR, Mid, yM);
   if (int rc = band_solve_impl(Mid, p.n_mid, p.bm, yM, n_rhs, st_M, st)) return rc;
