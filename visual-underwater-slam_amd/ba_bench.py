@@ -150,7 +150,7 @@ def run(device, n_kf=2000, n_lm=50000, obs_per_kf=1000, with_breakdown=True, rep
         "value_is": f"LM loop on the resident packed problem, median of {reps}",
         "value_cold": round(rep.seconds + setup, 4),
         "value_cold_is": "pack + block structure (structure_setup_s, warm) + LM loop, from arrays already in HBM",
-        "config": {"workload": "configs[2]: stereo BA, synthetic lawn-mower sweep", "keyframes": n_kf,
+        "config": {"workload": ("configs[2]" if n_kf == 2000 else f"{n_kf}-keyframe") + ": stereo BA, synthetic lawn-mower sweep", "keyframes": n_kf,
                    "landmarks": nL, "stereo_factors": prob.n_obs, "band_blocks": prob.band,
                    "schur_blocks": prob.st["n_blocks"], "schur_pairs": prob.st["n_pairs"],
                    "size_note": f"{n_lm} landmarks are drawn and {obs_per_kf} observations per keyframe requested; landmarks "
