@@ -381,3 +381,52 @@ def test_one_sided_band_solve_with_the_two_launch_panel_step(gpu, monkeypatch):
                       _lib.current_stream_ptr())
             assert int(d_st.item()) == 0, (nP, B, n_rhs)
             assert relerr(d_r.cpu().numpy(), np.linalg.solve(A, rhs.T).T) < 1e-10, (nP, B, n_rhs)
+
+
+def _thin(seq, keep_frac, rng, single_obs_every=0):
+    """Ragged version of a synthetic sequence: a random subset of the observations (every keyframe keeps at least
+    12, landmarks that lose all observations are dropped and the rest renumbered); optionally every k-th landmark is
+    cut down to ONE observation (a track of length one constrains nothing but must not break the elimination)."""
+    n_obs = len(seq["obs_pose"])
+    keep = rng.random(n_obs) < keep_frac
+    for i in np.unique(seq["obs_pose"]):
+        idx = np.nonzero(seq["obs_pose"] == i)[0]
+        if keep[idx].sum() < 12:
+            keep[idx[:12]] = True
+    if single_obs_every:
+        for j in np.unique(seq["obs_point"])[::single_obs_every]:
+            idx = np.nonzero((seq["obs_point"] == j) & keep)[0]
+            keep[idx[1:]] = False
+    used = np.unique(seq["obs_point"][keep])
+    remap = -np.ones(len(seq["points_gt"]), np.int64)
+    remap[used] = np.arange(len(used))
+    out = dict(seq)
+    out["obs_pose"], out["meas"] = seq["obs_pose"][keep], seq["meas"][keep]
+    out["obs_point"] = remap[seq["obs_point"][keep]].astype(seq["obs_point"].dtype)
+    out["points_gt"], out["points_init"] = seq["points_gt"][used], seq["points_init"][used]
+    return out
+
+
+@pytest.mark.parametrize("n_kf,line_len,keep,single", [(301, 8, 0.6, 0), (173, 7, 0.8, 5), (90, None, 0.5, 3), (37, 5, 0.9, 2)])
+def test_lm_on_ragged_graphs_matches_oracle(gpu, oracle, n_kf, line_len, keep, single):
+    """Ragged inputs: random observation subsets, landmarks with a single observation, keyframe counts that are not
+    multiples of the 8-pose panel, with and without the two-sided solve -- same LM trajectory and optimum as the oracle."""
+    from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
+    rng = np.random.default_rng(n_kf)
+    kw = {} if line_len is None else {"line_len": line_len}
+    s = _thin(synth.ba_sequence(n_kf, 20 * n_kf, 120, **kw), keep, rng, single)
+    nL = len(s["points_gt"])
+    assert np.bincount(s["obs_point"], minlength=nL).min() >= 1
+    if single:
+        assert (np.bincount(s["obs_point"], minlength=nL) == 1).sum() >= 3
+    prob = StereoBAProblem(s["obs_pose"], s["obs_point"], s["meas"], n_kf, nL, s["K"], s["sigma"],
+                           prior_pose=[0], prior_T=s["poses_gt"][:1], prior_sigmas=s["prior_sigmas"][None])
+    sv = StereoBASolver(prob)
+    pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"]), torch.from_numpy(s["obs_point"]),
+                                   torch.from_numpy(s["meas"]), n_kf, nL)
+    P = oracle.BAProblem(pk, s["K"], s["sigma"], (np.array([0], np.int32), s["poses_gt"][:1], s["prior_sigmas"][None]))
+    poses, points, rep = sv.optimize(torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda())
+    oposes, opoints, orep = oracle.ba_lm_optimize(P, prob.band, s["poses_init"], s["points_init"])
+    same_lm_trajectory(rep.iterations, rep.outer, rep.tries, rep.status, rep.err_hist, orep)
+    assert np.allclose(rep.err_hist, orep["err_hist"], rtol=1e-7)
+    assert relerr(poses.cpu().numpy(), oposes) < 1e-6 and relerr(points.cpu().numpy(), opoints) < 1e-5
