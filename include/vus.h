@@ -166,6 +166,8 @@ int vus_triangulate(const double* feat, int n, const double* cam, const double* 
  *   "L-order": sorted by (point, pose); point_ptr is the CSR row pointer over it;
  *   "P-order": sorted by (pose, point); pose_ptr is the CSR row pointer over it.
  * Per-observation Jacobian products W, Y live in P-order.
+ * Empty inputs: n_points == 0 and n_obs == 0 are valid (a graph of pose priors only); the arrays and the
+ * buffers of an empty dimension may then be NULL.  pose_ptr is always required (n_poses + 1 entries).
  * ---------------------------------------------------------------------------------------- */
 typedef struct vus_ba_problem {
   int n_poses, n_points, n_obs, n_priors;

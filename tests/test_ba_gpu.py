@@ -430,3 +430,25 @@ def test_lm_on_ragged_graphs_matches_oracle(gpu, oracle, n_kf, line_len, keep, s
     same_lm_trajectory(rep.iterations, rep.outer, rep.tries, rep.status, rep.err_hist, orep)
     assert np.allclose(rep.err_hist, orep["err_hist"], rtol=1e-7)
     assert relerr(poses.cpu().numpy(), oposes) < 1e-6 and relerr(points.cpu().numpy(), opoints) < 1e-5
+
+
+def test_graph_without_landmarks_is_a_prior_only_problem(gpu, oracle):
+    """Empty stereo input (a graph of pose priors only, zero landmarks and zero observations): the landmark and
+    observation arrays are empty, the reduced camera system is block-diagonal, and LM lands on the prior poses."""
+    from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
+    s = synth.ba_sequence(5, 40, 20)
+    nP = 5
+    e_i, e_f = np.zeros(0, np.int32), np.zeros((0, 3))
+    pri = (np.arange(nP, dtype=np.int32), s["poses_gt"], np.repeat(s["prior_sigmas"][None], nP, 0))
+    prob = StereoBAProblem(e_i, e_i, e_f, nP, 0, s["K"], s["sigma"], prior_pose=pri[0], prior_T=pri[1], prior_sigmas=pri[2])
+    assert prob.n_obs == 0 and prob.n_points == 0 and prob.band == 0
+    sv = StereoBASolver(prob)
+    start = s["poses_init"]
+    poses, points, rep = sv.optimize(torch.from_numpy(start).cuda(), torch.zeros(0, 3, dtype=torch.float64).cuda())
+    pk = ba_pack.pack_observations(torch.from_numpy(e_i), torch.from_numpy(e_i), torch.from_numpy(e_f), nP, 0)
+    P = oracle.BAProblem(pk, s["K"], s["sigma"], pri)
+    oposes, opoints, orep = oracle.ba_lm_optimize(P, 0, start, np.zeros((0, 3)))
+    same_lm_trajectory(rep.iterations, rep.outer, rep.tries, rep.status, rep.err_hist, orep)
+    assert rep.status == 0 and points.shape == (0, 3) and rep.initial_error > 0.1
+    assert relerr(poses.cpu().numpy(), oposes) < 1e-9
+    assert np.abs(poses.cpu().numpy() - s["poses_gt"]).max() < 1e-6

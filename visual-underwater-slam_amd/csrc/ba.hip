@@ -1676,8 +1676,11 @@ int check_problem(const vus_ba_problem* P) {
               "bad sizes: poses=%d points=%d obs=%d priors=%d", P->n_poses, P->n_points, P->n_obs, P->n_priors);
   VUS_REQUIRE(P->K != nullptr, "K is null");
   VUS_REQUIRE(P->inv_sigma > 0.0, "inv_sigma=%g", P->inv_sigma);
+  // pose_ptr has n_poses + 1 entries and the per-pose kernels read it even for a graph without a stereo factor
+  VUS_REQUIRE(P->pose_ptr != nullptr, "pose_ptr is null");
+  if (P->n_points > 0) VUS_REQUIRE(P->point_ptr != nullptr, "point_ptr is null");
   if (P->n_obs > 0)
-    VUS_REQUIRE(P->meas && P->obs_pose && P->obs_point && P->point_ptr && P->obs_ppos && P->pose_ptr && P->pobs_lidx,
+    VUS_REQUIRE(P->meas && P->obs_pose && P->obs_point && P->point_ptr && P->obs_ppos && P->pobs_lidx,
                 "observation arrays are null");
   if (P->n_priors > 0) VUS_REQUIRE(P->prior_pose && P->prior_T && P->prior_w, "prior arrays are null");
   return VUS_OK;
@@ -1695,7 +1698,7 @@ extern "C" long long vus_ba_work_doubles(const vus_ba_problem* P) {
 extern "C" int vus_ba_error(const vus_ba_problem* P, const double* poses, const double* points, double* err,
                             double* work, void* stream) {
   if (int rc = check_problem(P)) return rc;
-  VUS_REQUIRE(poses && points && err && work, "null buffer");
+  VUS_REQUIRE(poses && (points || !P->n_points) && err && work, "null buffer");
   hipStream_t st = vus::as_stream(stream);
   const int nL = P->n_points;
   if (nL > 0)
@@ -1711,7 +1714,10 @@ extern "C" int vus_ba_linearize(const vus_ba_problem* P, const double* poses, co
                                 double* V, double* gl, double* Hpp, double* gp, double* err, double* work,
                                 void* stream) {
   if (int rc = check_problem(P)) return rc;
-  VUS_REQUIRE(poses && points && W && V && gl && Hpp && gp && err && work, "null buffer");
+  // a graph without landmarks (priors only) has empty per-landmark / per-observation arrays: those may be null
+  VUS_REQUIRE(poses && Hpp && gp && err && work, "null buffer");
+  VUS_REQUIRE((points && V && gl) || !P->n_points, "null landmark buffer");
+  VUS_REQUIRE(W || !P->n_obs, "null observation buffer");
   hipStream_t st = vus::as_stream(stream);
   const int nL = P->n_points;
   if (nL > 0) lin_points_kernel<<<cdiv(nL, 4), 256, 0, st>>>(*P, poses, points, W, V, gl, work);
@@ -1729,7 +1735,9 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
   VUS_REQUIRE(S != nullptr, "structure is null");
   VUS_REQUIRE(S->band >= 0 && S->band < pose_stride(*P) * P->n_poses + 1 && S->n_blocks >= 0 && S->n_pairs >= 0,
               "bad structure: band=%d blocks=%d pairs=%d", S->band, S->n_blocks, S->n_pairs);
-  VUS_REQUIRE(W && V && gl && Hpp && gp && Vinv && Y && Sband && gs, "null buffer");
+  VUS_REQUIRE(Hpp && gp && Sband && gs, "null buffer");
+  VUS_REQUIRE((V && gl && Vinv) || !P->n_points, "null landmark buffer");
+  VUS_REQUIRE((W && Y) || !P->n_obs, "null observation buffer");
   if (S->n_blocks > 0) VUS_REQUIRE(S->blk_ptr && S->blk_i && S->blk_k && S->pair_a && S->pair_b, "structure arrays are null");
   VUS_REQUIRE(lambda >= 0.0, "lambda=%g", lambda);
   hipStream_t st = vus::as_stream(stream);
@@ -2176,7 +2184,9 @@ extern "C" int vus_ba_band_solve_multi_split(double* Sband, int n_nodes, int ban
 extern "C" int vus_ba_backsub(const vus_ba_problem* P, const double* W, const double* Vinv, const double* gl,
                               const double* dp, double* dl, void* stream) {
   if (int rc = check_problem(P)) return rc;
-  VUS_REQUIRE(W && Vinv && gl && dp && dl, "null buffer");
+  VUS_REQUIRE(dp != nullptr, "null buffer");
+  VUS_REQUIRE((Vinv && gl && dl) || !P->n_points, "null landmark buffer");
+  VUS_REQUIRE(W || !P->n_obs, "null observation buffer");
   if (P->n_points > 0)
     backsub_kernel<<<cdiv(P->n_points, 4), 256, 0, vus::as_stream(stream)>>>(*P, W, Vinv, gl, dp, dl);
   VUS_CHECK_LAUNCH("ba_backsub");
@@ -2187,7 +2197,8 @@ extern "C" int vus_ba_eval_step(const vus_ba_problem* P, const double* poses, co
                                 const double* dl, double* new_poses, double* new_points, double* out, double* work,
                                 void* stream) {
   if (int rc = check_problem(P)) return rc;
-  VUS_REQUIRE(poses && points && dp && dl && new_poses && new_points && out && work, "null buffer");
+  VUS_REQUIRE(poses && dp && new_poses && out && work, "null buffer");
+  VUS_REQUIRE((points && dl && new_points) || !P->n_points, "null landmark buffer");
   hipStream_t st = vus::as_stream(stream);
   const int nP = P->n_poses, nL = P->n_points;
   retract_kernel<<<cdiv(nP > nL ? nP : (nL < 65536 ? nL : 65536), 256) + 1, 256, 0, st>>>(nP, nL, pose_stride(*P), poses, points, dp, dl,
