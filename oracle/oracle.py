@@ -292,6 +292,22 @@ def ba_linearize(P, poses, points):
     return {"W": W, "V": V, "gl": gl, "Hpp": Hpp, "gp": gp, "err": float(e[0])}
 
 
+def ba_structure(P, band):
+    """vus_ba_structure arrays (numpy dict, keys of ba_pack.build_structure) by the plain row-by-row statement."""
+    nP = P.n_poses
+    rb, rp = np.zeros(nP, np.int32), np.zeros(nP, np.int32)
+    _check(lib().vus_ba_structure_count_cpu(P.ref(), int(band), _p(rb), _p(rp)), "ba_structure_count")
+    bb = np.zeros(nP + 1, np.int32); bb[1:] = np.cumsum(rb)
+    pb = np.zeros(nP + 1, np.int32); pb[1:] = np.cumsum(rp)
+    nb, npair = int(bb[-1]), int(pb[-1])
+    out = {"band": int(band), "n_blocks": nb, "n_pairs": npair, "blk_ptr": np.zeros(nb + 1, np.int32),
+           "blk_i": np.zeros(nb, np.int32), "blk_k": np.zeros(nb, np.int32), "pair_a": np.zeros(npair, np.int32),
+           "pair_b": np.zeros(npair, np.int32)}
+    _check(lib().vus_ba_structure_fill_cpu(P.ref(), int(band), _p(bb), _p(pb), _p(out["blk_ptr"]), _p(out["blk_i"]),
+                                           _p(out["blk_k"]), _p(out["pair_a"]), _p(out["pair_b"])), "ba_structure_fill")
+    return out
+
+
 def ba_schur(P, band, lam, lin):
     S = _BAStructure(int(band), 0, 0, None, None, None, None, None)
     Vinv = np.zeros((P.n_points, 6)); Y = np.zeros((P.n_obs, 18))

@@ -268,6 +268,73 @@ int vus_ba_linearize_cpu(const vus_ba_problem* P, const double* poses, const dou
   return VUS_OK;
 }
 
+/* Block structure of the reduced camera system, row by row: the plain statement of what csrc/structure.hip builds
+ * (and of ba_pack.build_structure).  Pairs of row i: (slot s of pose i, observation b of the same landmark with
+ * pose k <= i); block = (i, k); blocks by ascending k, pairs of a block by ascending s. */
+int vus_ba_structure_count_cpu(const vus_ba_problem* P, int band, int* row_blocks, int* row_pairs) {
+  if (!P || !row_blocks || !row_pairs || band < 0) return VUS_E_INVALID;
+  int* cnt = (int*)calloc((size_t)band + 1, sizeof(int));
+  if (!cnt) return VUS_E_INVALID;
+  for (int i = 0; i < P->n_poses; ++i) {
+    memset(cnt, 0, sizeof(int) * ((size_t)band + 1));
+    int np = 0, nb = 0;
+    for (int s = P->pose_ptr[i]; s < P->pose_ptr[i + 1]; ++s) {
+      const int a = P->pobs_lidx[s];
+      for (int b = P->point_ptr[P->obs_point[a]]; b <= a; ++b) {
+        const int d = i - P->obs_pose[b];
+        if (d < 0 || d > band) { free(cnt); return VUS_E_INVALID; }
+        ++cnt[d];
+        ++np;
+      }
+    }
+    for (int d = 0; d <= band; ++d) nb += cnt[d] > 0;
+    row_blocks[i] = nb;
+    row_pairs[i] = np;
+  }
+  free(cnt);
+  return VUS_OK;
+}
+
+int vus_ba_structure_fill_cpu(const vus_ba_problem* P, int band, const int* blk_base, const int* pair_base,
+                              int* blk_ptr, int* blk_i, int* blk_k, int* pair_a, int* pair_b) {
+  if (!P || !blk_base || !pair_base || !blk_ptr || !blk_i || !blk_k || !pair_a || !pair_b || band < 0)
+    return VUS_E_INVALID;
+  int* cnt = (int*)calloc((size_t)band + 1, sizeof(int));
+  int* cur = (int*)calloc((size_t)band + 1, sizeof(int));
+  if (!cnt || !cur) { free(cnt); free(cur); return VUS_E_INVALID; }
+  for (int i = 0; i < P->n_poses; ++i) {
+    memset(cnt, 0, sizeof(int) * ((size_t)band + 1));
+    for (int s = P->pose_ptr[i]; s < P->pose_ptr[i + 1]; ++s) {
+      const int a = P->pobs_lidx[s];
+      for (int b = P->point_ptr[P->obs_point[a]]; b <= a; ++b) ++cnt[i - P->obs_pose[b]];
+    }
+    int q = blk_base[i], pos = pair_base[i];
+    for (int d = band; d >= 0; --d) {          /* ascending k */
+      cur[d] = pos;
+      if (cnt[d] > 0) {
+        blk_i[q] = i;
+        blk_k[q] = i - d;
+        blk_ptr[q] = pos;
+        ++q;
+        pos += cnt[d];
+      }
+    }
+    for (int s = P->pose_ptr[i]; s < P->pose_ptr[i + 1]; ++s) {
+      const int a = P->pobs_lidx[s];
+      for (int b = P->point_ptr[P->obs_point[a]]; b <= a; ++b) {
+        const int d = i - P->obs_pose[b];
+        pair_a[cur[d]] = s;
+        pair_b[cur[d]] = P->obs_ppos[b];
+        ++cur[d];
+      }
+    }
+  }
+  blk_ptr[blk_base[P->n_poses]] = pair_base[P->n_poses];
+  free(cnt);
+  free(cur);
+  return VUS_OK;
+}
+
 int vus_ba_schur_cpu(const vus_ba_problem* P, const vus_ba_structure* S, double lambda, const double* W,
                      const double* V, const double* gl, const double* Hpp, const double* gp, double* Vinv,
                      double* Y, double* Sband, double* gs) {

@@ -53,6 +53,15 @@ def test_c3_has_the_baseline_size(c3):
     assert prob.band >= 200 and prob.st["n_pairs"] > 5e7
 
 
+def test_c3_device_built_structure_equals_the_sorted_pair_construction(c3):
+    """The 57 M pair lists built by csrc/structure.hip at the BASELINE size, bit for bit against the torch construction."""
+    s, prob, sv = c3
+    ref = ba_pack.build_structure(prob.pk)
+    assert (prob.st["n_blocks"], prob.st["n_pairs"]) == (ref["n_blocks"], ref["n_pairs"])
+    for k in ("blk_ptr", "blk_i", "blk_k", "pair_a", "pair_b"):
+        assert torch.equal(prob.st[k], ref[k]), k
+
+
 def test_c3_linearisation_matches_oracle_on_a_landmark_sample(c3, oracle):
     s, prob, sv = c3
     sv.linearize(torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda())

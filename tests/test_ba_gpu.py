@@ -452,3 +452,41 @@ def test_graph_without_landmarks_is_a_prior_only_problem(gpu, oracle):
     assert rep.status == 0 and points.shape == (0, 3) and rep.initial_error > 0.1
     assert relerr(poses.cpu().numpy(), oposes) < 1e-9
     assert np.abs(poses.cpu().numpy() - s["poses_gt"]).max() < 1e-6
+
+
+@pytest.mark.parametrize("case", [(30, 200, 10, 6), (64, 500, 64, 20), (7, 40, 7, 7), (700, 900, 600, 12), (3, 5000, 3, 3)])
+def test_device_structure_builder_is_bit_identical_to_the_sorted_pair_construction(gpu, oracle, case):
+    """csrc/structure.hip (per-row stable counting sort through a bit matrix) against ba_pack.build_structure (torch:
+    every pair materialised and sorted) and the oracle's row-by-row statement: identical index arrays.  Cases: narrow and
+    full-width bands, a band of 600 poses (fewer than 32 bit-words per block row in LDS: several passes per row), rows
+    with more than 1024 observations (several passes), landmarks seen once."""
+    from test_ba_oracle import random_cooccurrence, STRUCT_KEYS
+    from visual_underwater_slam_amd.ba import build_structure_device
+    n_poses, n_points, window, max_obs = case
+    op, ol = random_cooccurrence(np.random.default_rng(n_poses), n_poses, n_points, window, max_obs)
+    pk = ba_pack.pack_observations(torch.from_numpy(op).cuda(), torch.from_numpy(ol).cuda(),
+                                   torch.zeros(len(op), 3, dtype=torch.float64).cuda(), n_poses, n_points)
+    ref = ba_pack.build_structure(pk)
+    got = build_structure_device(pk)
+    torch.cuda.synchronize()
+    assert (got["band"], got["n_blocks"], got["n_pairs"]) == (ref["band"], ref["n_blocks"], ref["n_pairs"])
+    for k in STRUCT_KEYS:
+        assert torch.equal(got[k], ref[k]), k
+    P = oracle.BAProblem({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in pk.items()},
+                         np.array([400.0, 400, 0, 320, 240, 0.1]), 1.0)
+    cpu = oracle.ba_structure(P, ref["band"])
+    for k in STRUCT_KEYS:
+        assert np.array_equal(got[k].cpu().numpy(), cpu[k]), k
+
+
+def test_device_structure_builder_on_the_synthetic_sequences(gpu):
+    """Same comparison on the sequences the other tests solve (ragged rows, 2300 observations per pose)."""
+    from visual_underwater_slam_amd.ba import build_structure_device
+    for size in [(50, 500, 100), (8, 4000, 2500), (301, 6020, 120)]:
+        s = synth.ba_sequence(*size)
+        pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"]).cuda(), torch.from_numpy(s["obs_point"]).cuda(),
+                                       torch.from_numpy(s["meas"]).cuda(), size[0], len(s["points_gt"]))
+        ref, got = ba_pack.build_structure(pk), build_structure_device(pk)
+        assert (got["band"], got["n_blocks"], got["n_pairs"]) == (ref["band"], ref["n_blocks"], ref["n_pairs"])
+        for k in ("blk_ptr", "blk_i", "blk_k", "pair_a", "pair_b"):
+            assert torch.equal(got[k], ref[k]), (size, k)

@@ -217,6 +217,37 @@ def test_pack_and_structure_invariants():
         ba_pack.pack_observations(torch.tensor([0, 0]), torch.tensor([1, 1]), torch.zeros(2, 3, dtype=torch.float64), 2, 2)
 
 
+def random_cooccurrence(rng, n_poses, n_points, window, max_obs):
+    """Random (pose, point) observation lists: every point is seen by 1..max_obs distinct poses inside a window of
+    `window` poses placed at random (no geometry: index plumbing tests only)."""
+    op, ol = [], []
+    for j in range(n_points):
+        w0 = int(rng.integers(0, max(1, n_poses - window + 1)))
+        m = int(rng.integers(1, max_obs + 1))
+        poses = rng.choice(np.arange(w0, min(n_poses, w0 + window)), size=min(m, min(n_poses, w0 + window) - w0), replace=False)
+        op += list(poses); ol += [j] * len(poses)
+    return np.array(op, np.int64), np.array(ol, np.int64)
+
+
+STRUCT_KEYS = ("blk_ptr", "blk_i", "blk_k", "pair_a", "pair_b")
+
+
+@pytest.mark.parametrize("case", [(30, 200, 10, 6), (64, 500, 64, 20), (7, 40, 7, 7), (120, 300, 3, 3)])
+def test_row_by_row_structure_equals_the_sorted_pair_construction(oracle, case):
+    """oracle/vus_oracle_ba.c vus_ba_structure_*_cpu (the statement csrc/structure.hip implements) against
+    ba_pack.build_structure (all pairs, sorted by block key): identical arrays."""
+    n_poses, n_points, window, max_obs = case
+    op, ol = random_cooccurrence(np.random.default_rng(n_poses), n_poses, n_points, window, max_obs)
+    pk = ba_pack.pack_observations(torch.from_numpy(op), torch.from_numpy(ol), torch.zeros(len(op), 3, dtype=torch.float64),
+                                   n_poses, n_points)
+    st = ba_pack.build_structure(pk)
+    P = oracle.BAProblem(pk, np.array([400.0, 400, 0, 320, 240, 0.1]), 1.0)
+    got = oracle.ba_structure(P, st["band"])
+    assert (got["n_blocks"], got["n_pairs"]) == (st["n_blocks"], st["n_pairs"])
+    for k in STRUCT_KEYS:
+        assert np.array_equal(got[k], st[k].numpy()), k
+
+
 def test_multithreaded_cpu_port_equals_the_scalar_oracle(oracle):
     """oracle/ba_port.py + vus_oracle_ba_mt.c (the cpu_baseline "port": OpenMP kernels + LAPACK banded Cholesky)
     walks the same LM trajectory to the same optimum as the scalar oracle; stage outputs agree to round-off."""

@@ -1,4 +1,5 @@
-import sys,time; sys.path.insert(0,".")
+"""Set-up cost of a stereo BA problem at configs[2]: pack, structure (torch vs device builder), torch breakdown."""
+import sys,time; sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import torch
 from visual_underwater_slam_amd import synth, ba_pack
 s=synth.ba_sequence(2000,50000,1000)
@@ -9,7 +10,10 @@ for rep in range(3):
     torch.cuda.synchronize(); t=time.perf_counter()
     pk=ba_pack.pack_observations(op,ol,me,2000,nL); torch.cuda.synchronize(); t1=time.perf_counter()
     st=ba_pack.build_structure(pk); torch.cuda.synchronize(); t2=time.perf_counter()
-    print(f"rep{rep}: pack {1e3*(t1-t):.1f} ms, structure {1e3*(t2-t1):.1f} ms")
+    from visual_underwater_slam_amd.ba import build_structure_device
+    st2=build_structure_device(pk); torch.cuda.synchronize(); t3=time.perf_counter()
+    print(f"rep{rep}: pack {1e3*(t1-t):.1f} ms, structure (torch) {1e3*(t2-t1):.1f} ms, structure (csrc/structure.hip) {1e3*(t3-t2):.1f} ms")
+    del st, st2
 # finer breakdown of build_structure
 pkk=pk
 import torch

@@ -26,6 +26,8 @@ SIGNATURES = {
     "vus_track_ids": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
     # bundle adjustment (struct arguments are passed by address)
     "vus_ba_linearize": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "vus_ba_structure_count": [_P, c_int, _P, _P, _P],
+    "vus_ba_structure_fill": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P],
     "vus_ba_schur": [_P, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "vus_ba_add_diag": [_P, c_int, c_int, c_double, _P],
     "vus_ba_band_solve": [_P, c_int, c_int, _P, _P, _P, _P],

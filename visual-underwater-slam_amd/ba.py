@@ -69,6 +69,45 @@ def _i32(t):
     return t.to(torch.int32).contiguous()
 
 
+STRUCTURE_MAX_BAND = 6142        # widest band (poses) csrc/structure.hip keeps per row in LDS
+
+
+def build_structure_device(pk):
+    """vus_ba_structure of a packed problem, built by the HIP kernels of csrc/structure.hip: same dict, same contents
+    (bit for bit) as ba_pack.build_structure(pk), without materialising and sorting the co-observation pairs on the
+    host side.  Bands wider than STRUCTURE_MAX_BAND poses take the torch construction."""
+    n_obs, nP = pk["n_obs"], pk["n_poses"]
+    if n_obs == 0:
+        return ba_pack.build_structure(pk)
+    op, pptr = pk["obs_pose"], pk["point_ptr"].to(torch.int64)
+    seen = pptr[1:] > pptr[:-1]
+    first, last = op[pptr[:-1][seen]], op[pptr[1:][seen] - 1]
+    band = int((last - first).max().item())
+    if band > STRUCTURE_MAX_BAND:
+        return ba_pack.build_structure(pk)
+    dev = op.device
+    p = _lib.ptr
+    # only the index arrays of the problem are read
+    cp = _CProblem(nP, pk["n_points"], n_obs, 0, None, 1.0, None, p(pk["obs_pose"]), p(pk["obs_point"]),
+                   p(pk["point_ptr"]), p(pk["obs_ppos"]), p(pk["pose_ptr"]), p(pk["pobs_lidx"]), None, None, None, 1)
+    rows = torch.empty((2, nP), dtype=torch.int32, device=dev)
+    st_ptr = _lib.current_stream_ptr()
+    _lib.call("vus_ba_structure_count", ctypes.addressof(cp), band, p(rows[0]), p(rows[1]), st_ptr)
+    base = torch.zeros((2, nP + 1), dtype=torch.int64, device=dev)
+    torch.cumsum(rows, 1, out=base[:, 1:])
+    n_blocks, n_pairs = (int(v) for v in base[:, nP].tolist())
+    if n_pairs >= 2 ** 31:
+        raise NotImplementedError(f"{n_pairs} co-observation pairs exceed the int32 pair index")
+    base = base.to(torch.int32)
+    i32 = dict(dtype=torch.int32, device=dev)
+    st = {"band": band, "n_blocks": n_blocks, "n_pairs": n_pairs, "blk_ptr": torch.empty(n_blocks + 1, **i32),
+          "blk_i": torch.empty(n_blocks, **i32), "blk_k": torch.empty(n_blocks, **i32),
+          "pair_a": torch.empty(n_pairs, **i32), "pair_b": torch.empty(n_pairs, **i32)}
+    _lib.call("vus_ba_structure_fill", ctypes.addressof(cp), band, p(base[0]), p(base[1]), p(st["blk_ptr"]),
+              p(st["blk_i"]), p(st["blk_k"]), p(st["pair_a"]), p(st["pair_b"]), st_ptr)
+    return st
+
+
 class StereoBAProblem:
     """Packed, device-resident stereo BA problem (vus_ba_problem + vus_ba_structure)."""
 
@@ -83,7 +122,7 @@ class StereoBAProblem:
             return torch.as_tensor(x).to(device=dev, dtype=dt).contiguous()
         pk = ba_pack.pack_observations(to_dev(obs_pose, torch.int64), to_dev(obs_point, torch.int64),
                                        to_dev(meas, torch.float64), n_poses, n_points)
-        st = ba_pack.build_structure(pk)
+        st = build_structure_device(pk)
         self.pk, self.st = pk, st
         self.device = dev
         self.n_poses, self.n_points, self.n_obs = int(n_poses), int(n_points), pk["n_obs"]
