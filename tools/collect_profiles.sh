@@ -30,4 +30,9 @@ bash $ROOT/tools/pmc_ba.sh $OUT/pmc_ba_${TAG}.txt || true
 # 5. VALU issue-rate micro-benchmark (what bounds the FAST kernel) and the f64 matrix / vector rates (BA rooflines)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $ROOT/tools/ubench/valu_rate.hip -o /tmp/valu_rate 2>/dev/null && /tmp/valu_rate > $OUT/valu_issue_rates_${TAG}.txt || true
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $ROOT/tools/ubench/mfma_f64_rate.hip -o /tmp/mfma_f64_rate 2>/dev/null && /tmp/mfma_f64_rate > $OUT/mfma_f64_rate_${TAG}.txt || true
+/opt/rocm/bin/hipcc -O3 -w --offload-arch=gfx950 $ROOT/tools/ubench/lds_add_f64_rate.hip -o /tmp/lds_add_f64_rate 2>/dev/null && /tmp/lds_add_f64_rate > $OUT/lds_add_f64_rate_${TAG}.txt || true
+# 6. set-up of a configs[2] problem: pack, pair lists (torch sort vs csrc/structure.hip) with the kernel durations
+rm -rf /tmp/prof_st && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_st -- python3 $ROOT/tools/setup_prof.py > $OUT/setup_${TAG}.txt 2>/dev/null || true
+python3 $ROOT/tools/summarize_stats.py /tmp/prof_st 60 | grep -i "structure_rows\|kernel   " >> $OUT/setup_${TAG}.txt || true
+python3 $ROOT/tools/overlap_probe.py 2>/dev/null | tail -2 > $OUT/schur_band_overlap_${TAG}.txt || true
 ls -la $OUT
