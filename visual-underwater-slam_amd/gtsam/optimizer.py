@@ -185,10 +185,10 @@ def _pack_graph(graph, values, device=None):
     if imu_f or dvl_f:
         nav, prior_vec = _pack_nav(values, pose_keys, imu_f, dvl_f, prior_vec)
     aux = _AuxPriors()
-    lm_set = set(lm_keys.tolist())
     for f in prior_vec:
         k = f._keys[0]
-        if k in lm_set:
+        j = int(np.searchsorted(lm_keys, k))
+        if j < len(lm_keys) and lm_keys[j] == k:      # lm_keys ascend (unique)
             raise NotImplementedError("a prior factor on a landmark observed by stereo factors is not supported yet")
         if not values.exists(k):
             raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(k)}\", which does not exist in the Values.")
