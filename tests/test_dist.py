@@ -99,10 +99,16 @@ def _sharded_oracle_worker(rank, world, lam):
     lin = O.ba_linearize(P, seq["poses_init"], seq["points_init"][lo:hi])
     sch = O.ba_schur(P, band, lam, lin)
     S, gs, err = torch.from_numpy(sch["Sband"]), torch.from_numpy(sch["gs"]), torch.tensor([lin["err"]], dtype=torch.float64)
-    vdist.allreduce_sum(S); vdist.allreduce_sum(gs); vdist.allreduce_sum(err)
+    # the product's exchange step: reduce to rank 0, which solves and broadcasts its step and status
+    vdist.reduce_sum_to_rank0(S); vdist.reduce_sum_to_rank0(gs); vdist.allreduce_sum(err)
     Sn = S.numpy()
-    O.lib().vus_ba_add_diag_cpu(O._p(Sn), nP, band, O.c_double(-(world - 1) * lam))
-    dp, status, _ = O.ba_band_solve(Sn, gs.numpy())
+    dp_t, st_t = torch.zeros((nP, 6), dtype=torch.float64), torch.zeros(1, dtype=torch.int32)
+    if rank == 0:
+        O.lib().vus_ba_add_diag_cpu(O._p(Sn), nP, band, O.c_double(-(world - 1) * lam))
+        dp0, status0, _ = O.ba_band_solve(Sn, gs.numpy())
+        dp_t.copy_(torch.from_numpy(dp0)); st_t[0] = status0
+    vdist.broadcast_from_rank0(dp_t); vdist.broadcast_from_rank0(st_t)
+    dp, status = dp_t.numpy(), int(st_t[0])
     dl = O.ba_backsub(P, lin, sch["Vinv"], dp)
     full = torch.zeros((nL, 3), dtype=torch.float64)
     full[lo:hi] = torch.from_numpy(dl)
@@ -111,7 +117,7 @@ def _sharded_oracle_worker(rank, world, lam):
 
 
 @pytest.mark.parametrize("world", [2, 3])
-def test_landmark_sharded_schur_allreduce_equals_single_rank(oracle, world):
+def test_landmark_sharded_schur_reduce_equals_single_rank(oracle, world):
     lam = 0.37
     out = _run(_sharded_oracle_worker, world, lam)
     seq = synth.ba_sequence(40, 400, 80)
@@ -127,12 +133,13 @@ def test_landmark_sharded_schur_allreduce_equals_single_rank(oracle, world):
     for r in range(world):
         S, gs, err, dpr, dlr, str_ = out[r]
         scale = np.abs(sch["Sband"]).max()
-        assert np.abs(S - sch["Sband"]).max() < 1e-9 * scale          # fp64 reduction-order noise only
-        assert np.allclose(gs, sch["gs"], rtol=1e-9, atol=1e-9 * np.abs(sch["gs"]).max())
+        if r == 0:                                                        # the reduced system lives on rank 0 only
+            assert np.abs(S - sch["Sband"]).max() < 1e-9 * scale          # fp64 reduction-order noise only
+            assert np.allclose(gs, sch["gs"], rtol=1e-9, atol=1e-9 * np.abs(sch["gs"]).max())
         assert np.isclose(err, lin["err"], rtol=1e-12) and str_ == 0
         assert np.allclose(dpr, dp, rtol=1e-6, atol=1e-9 * np.abs(dp).max())
         assert np.allclose(dlr, dl, rtol=1e-6, atol=1e-9 * np.abs(dl).max())
-    assert np.array_equal(out[0][3], out[1][3])                       # replicated solve: identical on every rank
+    assert np.array_equal(out[0][3], out[1][3])                       # rank 0's step, bit for bit, on every rank
 
 
 def _gpu_sharded_worker(rank, world):
@@ -165,21 +172,19 @@ def test_sharded_lm_two_ranks_on_one_gpu_matches_single(gpu):
 
 
 def _status_worker(rank, world):
-    st = torch.tensor([0 if rank == 0 else -1], dtype=torch.int32)
-    vdist.allreduce_status(st)
-    st2 = torch.tensor([0 if rank == 0 else 58], dtype=torch.int32)
-    vdist.allreduce_status(st2)
+    st = torch.tensor([58 if rank == 0 else 0], dtype=torch.int32)
+    vdist.broadcast_from_rank0(st)
     x = torch.full((4,), float(rank + 1), dtype=torch.float64)
     vdist.broadcast_from_rank0(x)
-    return int(st[0]), int(st2[0]), x.tolist()
+    return int(st[0]), x.tolist()
 
 
-def test_status_agreement_and_step_broadcast_gloo_world2():
-    """A rank whose band solve gave up (-1) or met a non-positive pivot (k+1) makes EVERY rank see it, and rank 0's
-    step is the step on every rank (the replicated solve sums with f64 atomics: last bits differ between ranks)."""
+def test_step_and_status_broadcast_gloo_world2():
+    """Rank 0 solves the reduced system: its step and its status word (non-positive pivot k+1, or -1 for an expired
+    wait) are what every rank acts on, so all ranks accept / reject / raise together."""
     out = _run(_status_worker, 2)
     for r in range(2):
-        assert out[r] == (-1, 58, [1.0, 1.0, 1.0, 1.0])
+        assert out[r] == (58, [1.0, 1.0, 1.0, 1.0])
 
 
 def _frontend_shard_worker(rank, world, n_frames, H, W, K):

@@ -248,7 +248,7 @@ def run_full_graph(device, n_kf=2000, n_lm=50000, obs_per_kf=1000, kf_period=0.2
 
 
 def run_sharded(device, world, rank, n_kf=10000, n_lm=500000, obs_per_kf=1000):
-    """BASELINE.json configs[4]: landmark block-rows across the ranks, RCCL all-reduce of the reduced camera system
+    """BASELINE.json configs[4]: landmark block-rows across the ranks, RCCL reduce of the reduced camera system to rank 0, which solves it and broadcasts the step
     (dist.ShardedStereoBASolver).  Every rank generates the same deterministic sequence and keeps its landmark range.
     Returns this rank's LM seconds and the report; bench.py takes the maximum over ranks."""
     from . import synth, dist as vdist
@@ -269,7 +269,7 @@ def run_sharded(device, world, rank, n_kf=10000, n_lm=500000, obs_per_kf=1000):
         "config": {"workload": "configs[4]: landmark block-row partitioned Schur BA", "keyframes": n_kf, "landmarks": nL,
                    "stereo_factors": len(s["obs_pose"]), "band_blocks": sv.problem.band, "ranks": world,
                    "local_landmarks": sv.hi - sv.lo, "local_stereo_factors": sv.problem.n_obs,
-                   "allreduce_bytes_per_trial": band_bytes + 48 * n_kf},
+                   "reduce_to_rank0_bytes_per_trial": band_bytes + 48 * n_kf, "broadcast_bytes_per_trial": 48 * n_kf},
         "lm": {"iterations": rep.iterations, "linear_solves": rep.tries, "status": rep.status,
                "initial_error": rep.initial_error, "final_error": rep.final_error},
         "max_pose_error_m": float((poses[:, 9:].cpu() - torch.from_numpy(s["poses_gt"][:, 9:])).abs().max()),

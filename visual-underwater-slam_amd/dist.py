@@ -137,20 +137,14 @@ def _collective(t: torch.Tensor, fn):
     return t
 
 
-def allreduce_status(status: torch.Tensor):
-    """Worst band-solve status over the ranks, in place: the smallest one if any rank reports a negative code
-    (expired wait), else the largest (first non-positive pivot column + 1; 0 = ok)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
-        return status
-    mn, mx = status.clone(), status.clone()
-    _collective(mn, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MIN))
-    _collective(mx, lambda x: dist.all_reduce(x, op=dist.ReduceOp.MAX))
-    status.copy_(torch.where(mn < 0, mn, mx))
-    return status
-
-
 def broadcast_from_rank0(t: torch.Tensor):
     return _collective(t, lambda x: dist.broadcast(x, src=0))
+
+
+def reduce_sum_to_rank0(t: torch.Tensor):
+    """Sum over ranks delivered to rank 0 only (in place there; the other ranks' buffers are left in an unspecified
+    state): half the bytes per link of an all-reduce (no all-gather phase)."""
+    return _collective(t, lambda x: dist.reduce(x, dst=0))
 
 
 class ShardedStereoBASolver:
@@ -191,6 +185,7 @@ def _make_shard_solver():
         def __init__(self, problem, world):
             super().__init__(problem)
             self.world = world
+            self.rank = dist.get_rank() if dist.is_initialized() else 0
 
         def error(self, poses, points):
             super().error(poses, points)
@@ -203,23 +198,26 @@ def _make_shard_solver():
 
         def schur(self, lam):
             super().schur(lam)
-            # THE exchange step: reduced camera system (block band + rhs) summed over landmark shards
-            allreduce_sum(self.Sband)
-            allreduce_sum(self.gs)
+            # THE exchange step: the reduced camera system (block band + rhs) summed over the landmark shards.
+            # Only rank 0 solves it, so a reduce to rank 0 is enough: half the bytes per link of an all-reduce.
             if self.world > 1:
-                _lib.call("vus_ba_add_diag", _lib.ptr(self.Sband), self.P.n_poses, self.P.band,
-                          -(self.world - 1) * float(lam), _lib.current_stream_ptr())
+                reduce_sum_to_rank0(self.Sband)
+                reduce_sum_to_rank0(self.gs)
+                if self.rank == 0:            # every rank added its own lambda I
+                    _lib.call("vus_ba_add_diag", _lib.ptr(self.Sband), self.P.n_poses, self.P.band,
+                              -(self.world - 1) * float(lam), _lib.current_stream_ptr())
 
         def band_solve(self):
-            super().band_solve()
-            if self.world > 1:
-                # The solve is replicated, but its cooperative back-substitution sums with f64 atomics: ranks
-                # would drift apart in the last bits.  Rank 0's dp is THE step on every rank, and a rank whose
-                # solve reported a problem (status < 0: bounded wait expired; > 0: non-positive pivot) makes
-                # every rank see it, so that all of them raise / reject together instead of one rank leaving
-                # its peers blocked in the next collective.
-                broadcast_from_rank0(self.dp)
-                allreduce_status(self.status)
+            if self.world == 1:
+                return super().band_solve()
+            # Rank 0 solves; its step dp and its status word (< 0: bounded wait expired; > 0: non-positive pivot)
+            # are THE step and THE status on every rank, so that all ranks accept / reject / raise together.
+            # (A replicated solve would cost the same wall time, the all-gather half of an all-reduce on top, and
+            # its cooperative back-substitution -- f64 atomics -- would let the ranks drift apart in the last bits.)
+            if self.rank == 0:
+                super().band_solve()
+            broadcast_from_rank0(self.dp)
+            broadcast_from_rank0(self.status)
 
         def eval_step(self, poses, points):
             super().eval_step(poses, points)
