@@ -65,3 +65,58 @@ def test_fast_corner_set_and_orientation_bins_agree_with_scikit_image(oracle, tm
     clear = frac < 0.49                                              # away from a bin boundary
     assert clear.mean() > 0.95
     assert np.array_equal(ang.astype(np.int64)[clear], bins[clear])
+
+
+def test_ba_optimum_agrees_with_scipy_least_squares(oracle):
+    """Independent pin of the BA cost function and its optimum: the same small stereo graph (GenericStereoFactor3D
+    residuals whitened by sigma, one PriorFactorPose3 on X0) written down again in numpy -- stereo projection from the
+    camera model, the prior through scipy's matrix logarithm of X0^-1 * prior instead of the oracle's closed-form
+    Pose3 Logmap -- and minimised by scipy.optimize.least_squares (MINPACK's Levenberg-Marquardt, then a trust-region polish) over rotation
+    vectors + translations.  Same cost at the start, same cost and same variables at the optimum.  It pins the residual
+    definitions and the optimum, not GTSAM's trial sequence (gtsam itself is absent: test_reference_engines.py)."""
+    import torch
+    from scipy.linalg import logm
+    from scipy.optimize import least_squares
+    from scipy.spatial.transform import Rotation
+    from visual_underwater_slam_amd import ba_pack
+    s = synth.ba_sequence(6, 80, 40, pose_sigma_t=0.03, pose_sigma_r=0.01)
+    nP, nL = 6, len(s["points_gt"])
+    fx, fy, _, cx, cy, b = s["K"]
+    op, ol, me = s["obs_pose"], s["obs_point"], s["meas"]
+    w_st, w_pr = 1.0 / s["sigma"], 1.0 / s["prior_sigmas"]
+    prior = np.eye(4); prior[:3, :3] = s["poses_gt"][0, :9].reshape(3, 3); prior[:3, 3] = s["poses_gt"][0, 9:]
+
+    def unpack(x):
+        R = Rotation.from_rotvec(x[:3 * nP].reshape(nP, 3)).as_matrix()
+        return R, x[3 * nP:6 * nP].reshape(nP, 3), x[6 * nP:].reshape(nL, 3)
+
+    def residuals(x):
+        R, t, p = unpack(x)
+        q = np.einsum("nji,nj->ni", R[op], p[ol] - t[op])              # R^T (p - t)
+        uL = cx + fx * q[:, 0] / q[:, 2]
+        uR = cx + fx * (q[:, 0] - b) / q[:, 2]
+        v = cy + fy * q[:, 1] / q[:, 2]
+        r_st = (np.stack([uL, uR, v], 1) - me) * w_st
+        X0 = np.eye(4); X0[:3, :3] = R[0]; X0[:3, 3] = t[0]
+        L = np.real(logm(np.linalg.inv(X0) @ prior))                    # se(3): [[w]x v; 0 0]
+        xi = np.array([L[2, 1], L[0, 2], L[1, 0], L[0, 3], L[1, 3], L[2, 3]])
+        return np.concatenate([r_st.ravel(), xi * w_pr])
+
+    x0 = np.concatenate([Rotation.from_matrix(s["poses_init"][:, :9].reshape(nP, 3, 3)).as_rotvec().ravel(),
+                         s["poses_init"][:, 9:].ravel(), s["points_init"].ravel()])
+    pk = ba_pack.pack_observations(torch.from_numpy(op), torch.from_numpy(ol), torch.from_numpy(me), nP, nL)
+    P = oracle.BAProblem(pk, s["K"], s["sigma"], (np.array([0], np.int32), s["poses_gt"][:1], s["prior_sigmas"][None]))
+    band = ba_pack.build_structure(pk)["band"]
+    assert np.isclose(0.5 * np.sum(residuals(x0) ** 2), oracle.ba_error(P, s["poses_init"], s["points_init"]), rtol=1e-10)
+    sol = least_squares(residuals, x0, method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15, max_nfev=20000)
+    # MINPACK's forward-difference Jacobian stalls at ~1e-6 relative; polish with central differences
+    sol = least_squares(residuals, sol.x, method="trf", jac="3-point", xtol=1e-15, ftol=1e-15, gtol=1e-12, max_nfev=200)
+    poses, points = s["poses_init"], s["points_init"]
+    for _ in range(3):          # gtsam's default relative tolerance 1e-5 stops early: restart until converged
+        poses, points, rep = oracle.ba_lm_optimize(P, band, poses, points)
+    assert rep["status"] == 0
+    assert np.isclose(sol.cost, rep["final_error"], rtol=1e-8)
+    R, t, p = unpack(sol.x)
+    assert np.abs(R.reshape(nP, 9) - poses[:, :9]).max() < 1e-6
+    assert np.abs(t - poses[:, 9:]).max() < 1e-6
+    assert np.abs(p - points).max() < 1e-5
