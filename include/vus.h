@@ -257,7 +257,8 @@ int vus_ba_linearize(const vus_ba_problem* P, const double* poses, const double*
                      double* work, void* stream);
 
 /* Damped landmark elimination for one lambda (lambda*I damping, gtsam diagonalDamping=false):
- *   Vinv [n_points,6] = (V + lambda I)^-1 (upper triangle);  Y [n_obs,18] = W Vinv (P-order);
+ *   Vinv [n_points,6] = (V + lambda I)^-1 (upper triangle);  Y [n_obs,18] = W Vinv (P-order), OPTIONAL output
+ *   (NULL: not written; the kernels form the rows they need on the fly);
  *   S band (see vus_ba_structure) = Hpp + lambda I - sum_j Y W^T;  gs [n_poses,6] = gp - sum Y gl. */
 int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lambda,
                  const double* W, const double* V, const double* gl, const double* Hpp,

@@ -168,7 +168,6 @@ class StereoBASolver:
         nN = problem.n_nodes                       # camera-side nodes (= poses unless velocity nodes are interleaved)
         f64 = dict(dtype=torch.float64, device=dev)
         self.W = torch.empty((nO, 18), **f64)
-        self.Y = torch.empty((nO, 18), **f64)
         self.V = torch.empty((nL, 6), **f64)
         self.Vinv = torch.empty((nL, 6), **f64)
         self.gl = torch.empty((nL, 3), **f64)
@@ -210,10 +209,12 @@ class StereoBASolver:
         _lib.call("vus_ba_linearize", self._pp(), p(poses), p(points), p(self.W), p(self.V), p(self.gl),
                   p(self.Hpp), p(self.gp), p(self.scal), p(self.work), _lib.current_stream_ptr())
 
-    def schur(self, lam: float):
+    def schur(self, lam: float, Y=None):
+        """Y: optional [n_obs,18] buffer that receives W Vinv (P-order); the kernels form it on the fly and need no
+        such array (277 MB at configs[2])."""
         p = _lib.ptr
         _lib.call("vus_ba_schur", self._pp(), ctypes.addressof(self.P.c_structure), float(lam), p(self.W), p(self.V),
-                  p(self.gl), p(self.Hpp), p(self.gp), p(self.Vinv), p(self.Y), p(self.Sband), p(self.gs),
+                  p(self.gl), p(self.Hpp), p(self.gp), p(self.Vinv), p(Y), p(self.Sband), p(self.gs),
                   _lib.current_stream_ptr())
 
     def band_solve(self):

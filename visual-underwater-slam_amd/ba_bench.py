@@ -55,7 +55,7 @@ def roofline(prob, stage_ms):
     nO, nL, nP, B = prob.n_obs, prob.n_points, prob.n_poses, prob.band
     nblk, npair, nN = prob.st["n_blocks"], prob.st["n_pairs"], prob.n_nodes
     lin_bytes = nO * (32 + 144) + nP * (96 + 288 + 48) + nL * (24 + 72 + 24)
-    schur_bytes = 144 * nO * 2 + 72 * nL + 288 * nblk            # W and Y once each, V^-1, the S blocks written
+    schur_bytes = 144 * nO + 72 * nL + 288 * nblk                # W once (Y = W V^-1 is formed on the fly), V^-1, the S blocks written
     schur_flops = 2.0 * 108 * npair + 2.0 * 54 * nO              # 6x3 * 3x6 per co-observation pair + Y = W V^-1
     band_bytes = 2.0 * 288 * nN * (B + 1) + 288 * nN * (B + 1)   # factor read + written, read again by the back-substitution
     fl, launches = band_factor_flops(nN, B)

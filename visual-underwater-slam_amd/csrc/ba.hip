@@ -453,8 +453,10 @@ __device__ __forceinline__ int lower_bound_wave(const int* __restrict__ a, int n
 constexpr int SR_MAXB = 512;      // blocks of a row that get scheduled largest first (more: natural order)
 
 __global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure S, const int* __restrict__ pose_ptr,
+                                                                const int* __restrict__ pobs_lidx,
+                                                                const int* __restrict__ obs_point,
                                                                 int n_rows, int ps, const double* __restrict__ W,
-                                                                const double* __restrict__ Y,
+                                                                const double* __restrict__ Vinv,
                                                                 double* __restrict__ Sband) {
   extern __shared__ double s_y[];          // [rows of the chunk][SR_LD]
   __shared__ int s_b0, s_b1, s_next;
@@ -508,14 +510,19 @@ __global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure
       if (c0 > a0) __syncthreads();    // the previous chunk has been consumed
       if (tid == 0) s_next = 0;
       {
-        // rows of 18 doubles land SR_LD = 19 doubles apart: with a stride of 36 dwords the 32 rows one read
+        // The pose's own rows Y_s = W_s Vinv_j(s) are formed while they are staged (task = one 1x3 row of a 6x3
+        // block: three consecutive doubles of W, coalesced across the tasks): Y = W Vinv is never written to memory.
+        // Rows of 18 doubles land SR_LD = 19 doubles apart: with a stride of 36 dwords the 32 rows one read
         // instruction touches fall on 16 bank groups and collide (PMC: 69 % of the LDS cycles were bank conflicts)
-        const d2_t* src = reinterpret_cast<const d2_t*>(Y + 18 * (size_t)c0);
-        for (int t = tid; t < 9 * (c1 - c0); t += SR_THREADS) {
-          const d2_t v = src[t];
-          const int row = t / 9, h = t - 9 * row;
-          s_y[SR_LD * row + 2 * h] = v.x;
-          s_y[SR_LD * row + 2 * h + 1] = v.y;
+        const double* src = W + 18 * (size_t)c0;
+        for (int t = tid; t < 6 * (c1 - c0); t += SR_THREADS) {
+          const int row = t / 6, rr = t - 6 * row;
+          const double* vi = Vinv + 6 * (size_t)obs_point[pobs_lidx[c0 + row]];
+          const double w0 = src[3 * t], w1 = src[3 * t + 1], w2 = src[3 * t + 2];
+          double* dst = s_y + SR_LD * row + 3 * rr;
+          dst[0] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
+          dst[1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
+          dst[2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
         }
       }
       __syncthreads();
@@ -603,8 +610,9 @@ __global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure
   }   // rows of this workgroup
 }
 
-// gs_i = gp_i - sum_{slots of pose i} Y_s gl[point(s)]   (one wave per pose)
-__global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const double* __restrict__ Y,
+// gs_i = gp_i - sum_{slots of pose i} W_s (Vinv gl)[point(s)]   (one wave per pose)
+__global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const double* __restrict__ W,
+                                                       const double* __restrict__ Vinv,
                                                        const double* __restrict__ gl,
                                                        const double* __restrict__ gp, double* __restrict__ gs) {
   const int i = blockIdx.x;
@@ -612,10 +620,14 @@ __global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const d
   double acc[6] = {0, 0, 0, 0, 0, 0};
   for (int s = P.pose_ptr[i] + lane; s < P.pose_ptr[i + 1]; s += 64) {
     const int j = P.obs_point[P.pobs_lidx[s]];
+    const double* vi = Vinv + 6 * (size_t)j;
     const double g0 = gl[3 * (size_t)j], g1 = gl[3 * (size_t)j + 1], g2 = gl[3 * (size_t)j + 2];
-    const double* Ys = Y + 18 * (size_t)s;
+    const double t0 = vi[0] * g0 + vi[1] * g1 + vi[2] * g2;
+    const double t1 = vi[1] * g0 + vi[3] * g1 + vi[4] * g2;
+    const double t2 = vi[2] * g0 + vi[4] * g1 + vi[5] * g2;
+    const double* Ws = W + 18 * (size_t)s;
 #pragma unroll
-    for (int rr = 0; rr < 6; ++rr) acc[rr] += Ys[3 * rr] * g0 + Ys[3 * rr + 1] * g1 + Ys[3 * rr + 2] * g2;
+    for (int rr = 0; rr < 6; ++rr) acc[rr] += Ws[3 * rr] * t0 + Ws[3 * rr + 1] * t1 + Ws[3 * rr + 2] * t2;
   }
 #pragma unroll
   for (int rr = 0; rr < 6; ++rr) acc[rr] = wave_sum(acc[rr]);
@@ -1737,7 +1749,7 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
               "bad structure: band=%d blocks=%d pairs=%d", S->band, S->n_blocks, S->n_pairs);
   VUS_REQUIRE(Hpp && gp && Sband && gs, "null buffer");
   VUS_REQUIRE((V && gl && Vinv) || !P->n_points, "null landmark buffer");
-  VUS_REQUIRE((W && Y) || !P->n_obs, "null observation buffer");
+  VUS_REQUIRE(W || !P->n_obs, "null observation buffer");
   if (S->n_blocks > 0) VUS_REQUIRE(S->blk_ptr && S->blk_i && S->blk_k && S->pair_a && S->pair_b, "structure arrays are null");
   VUS_REQUIRE(lambda >= 0.0, "lambda=%g", lambda);
   hipStream_t st = vus::as_stream(stream);
@@ -1746,7 +1758,7 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
   VUS_CHECK_HIP(hipMemsetAsync(Sband, 0, sizeof(double) * 36 * (size_t)nP * ps * (S->band + 1), st));
   if (ps > 1) VUS_CHECK_HIP(hipMemsetAsync(gs, 0, sizeof(double) * 6 * (size_t)nP * ps, st));
   if (nL > 0) vinv_kernel<<<cdiv(nL, 256), 256, 0, st>>>(nL, lambda, V, Vinv);
-  if (nO > 0) ymul_kernel<<<cdiv(nO, 256), 256, 0, st>>>(*P, W, Vinv, Y);
+  if (nO > 0 && Y != nullptr) ymul_kernel<<<cdiv(nO, 256), 256, 0, st>>>(*P, W, Vinv, Y);   // optional output only
   schur_init_kernel<<<cdiv(36ll * nP, 256), 256, 0, st>>>(nP, S->band, ps, lambda, Hpp, Sband);
   if (S->n_blocks > 0) {
     static bool lds_set = false;
@@ -1764,9 +1776,9 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
     }
     int wg = 8 * (n_cu / 8);
     if (wg > 8 * ((nP + 7) / 8)) wg = 8 * ((nP + 7) / 8);
-    schur_rows_kernel<<<wg, SR_THREADS, lds, st>>>(*S, P->pose_ptr, nP, ps, W, Y, Sband);
+    schur_rows_kernel<<<wg, SR_THREADS, lds, st>>>(*S, P->pose_ptr, P->pobs_lidx, P->obs_point, nP, ps, W, Vinv, Sband);
   }
-  schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, Y, gl, gp, gs);
+  schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, W, Vinv, gl, gp, gs);
   VUS_CHECK_LAUNCH("ba_schur");
   return VUS_OK;
 }
