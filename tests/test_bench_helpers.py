@@ -3,6 +3,8 @@ parses must come out well-formed whatever the stage times are."""
 import json
 import types
 
+import pytest
+
 import bench
 from visual_underwater_slam_amd import ba_bench
 
@@ -36,3 +38,25 @@ def test_measured_counters_reads_the_committed_pmc_summary():
     traffic, valu, ns = bench.measured_counters("fast_detect", 1000)
     assert traffic and traffic > 2 * 720 * 1280 * 1000 and valu and valu > 1e9 and 1.0 < ns < 2.5
     assert bench.measured_counters("hamming_track", 10)[0] > 0
+
+
+@pytest.mark.gpu
+def test_bench_command_line_contract_on_a_small_stream(gpu):
+    """`python bench.py` end to end (the driver's command, with a small stream so that it takes seconds): ONE JSON line
+    with the contract's keys, the roofline object of the dominant kernel and the BA legs."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--frames", "24", "--steps", "2", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    j = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["steps"] == 2 and j["warmup"] == 1 and j["value"] > 0 and j["higher_is_better"] is True
+    assert j["roofline"]["bound"] in ("hbm", "mfma") and 0 < j["roofline"]["frac"] < 1
+    ba = j["ba"]
+    assert ba["lm"]["status"] == 0 and ba["value"] > 0 and ba["dropin"]["same_optimum_as_array_path"] is True
+    assert ba["roofline"]["bound"] in ("hbm", "mfma")
