@@ -50,6 +50,19 @@ __device__ __forceinline__ void scan_row(const int* hist, int* brank, int* poff,
   n_pair = __shfl(inp, 63);
 }
 
+// The partners of a slot are the consecutive L-order entries lo .. a of its landmark; four at a time, so that the
+// index loads of a step do not wait for one another.
+#define SB_WALK_RUN(LO, A, BODY)                                                    \
+  for (int b0_ = (LO); b0_ <= (A); b0_ += 4) {                                      \
+    int kq_[4];                                                                     \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) kq_[u_] = P.obs_pose[min(b0_ + u_, (A))]; \
+    _Pragma("unroll") for (int u_ = 0; u_ < 4; ++u_) {                              \
+      const int b = b0_ + u_;                                                       \
+      const int d = i - kq_[u_];                                                    \
+      if (b <= (A) && d >= 0 && d < nd) { BODY }                                    \
+    }                                                                               \
+  }
+
 // e = nd - 1 - d: ascending e = ascending k = the block order of the structure
 template <bool FILL>
 __global__ __launch_bounds__(SB_THREADS) void structure_rows_kernel(vus_ba_problem P, int nd, int words,
@@ -72,10 +85,8 @@ __global__ __launch_bounds__(SB_THREADS) void structure_rows_kernel(vus_ba_probl
   __syncthreads();
   for (int s = a0 + tid; s < a1; s += SB_THREADS) {
     const int a = P.pobs_lidx[s];
-    for (int b = P.point_ptr[P.obs_point[a]]; b <= a; ++b) {
-      const int d = i - P.obs_pose[b];
-      if (d >= 0 && d < nd) atomicAdd(&hist[nd - 1 - d], 1);
-    }
+    const int lo = P.point_ptr[P.obs_point[a]];
+    SB_WALK_RUN(lo, a, atomicAdd(&hist[nd - 1 - d], 1);)
   }
   __syncthreads();
   if (tid < 64) {
@@ -105,12 +116,10 @@ __global__ __launch_bounds__(SB_THREADS) void structure_rows_kernel(vus_ba_probl
     __syncthreads();
     for (int o = tid; o < n; o += SB_THREADS) {
       const int a = P.pobs_lidx[c0 + o];
+      const int lo = P.point_ptr[P.obs_point[a]];
       const int w = o >> 5;
       const unsigned bit = 1u << (o & 31);
-      for (int b = P.point_ptr[P.obs_point[a]]; b <= a; ++b) {
-        const int d = i - P.obs_pose[b];
-        if (d >= 0 && d < nd) atomicOr(&bits[(nd - 1 - d) * words + w], bit);
-      }
+      SB_WALK_RUN(lo, a, atomicOr(&bits[(nd - 1 - d) * words + w], bit);)
     }
     __syncthreads();
     for (int e = tid; e < nd; e += SB_THREADS) {
@@ -130,13 +139,23 @@ __global__ __launch_bounds__(SB_THREADS) void structure_rows_kernel(vus_ba_probl
       // backwards from the slot's own observation: step t of neighbouring slots then lands in the same block more
       // often than not (d = 0 first, then mostly the previous keyframe, ...), i.e. at neighbouring places of the lists
       const int lo = P.point_ptr[P.obs_point[a]];
-      for (int b = a; b >= lo; --b) {
-        const int d = i - P.obs_pose[b];
-        if (d >= 0 && d < nd) {
-          const int t = (nd - 1 - d) * words + w;
-          const int pos = pb + wpre[t] + __popc(bits[t] & below);
-          pair_a[pos] = s;
-          pair_b[pos] = P.obs_ppos[b];
+      for (int b0 = a; b0 >= lo; b0 -= 4) {
+        int kq[4], pq[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int b = max(b0 - u, lo);
+          kq[u] = P.obs_pose[b];
+          pq[u] = P.obs_ppos[b];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int d = i - kq[u];
+          if (b0 - u >= lo && d >= 0 && d < nd) {
+            const int t = (nd - 1 - d) * words + w;
+            const int pos = pb + wpre[t] + __popc(bits[t] & below);
+            pair_a[pos] = s;
+            pair_b[pos] = pq[u];
+          }
         }
       }
     }
