@@ -19,6 +19,8 @@ def pack_observations(obs_pose, obs_point, meas, n_poses, n_points):
     obs_point = obs_point.to(torch.int64)
     n_obs = obs_pose.numel()
     key = obs_point * n_poses + obs_pose
+    if int(n_points) * int(n_poses) < 2 ** 31:      # 32-bit keys: half the radix passes of the sort
+        key = key.to(torch.int32)
     key_sorted, perm = torch.sort(key, stable=True)
     if n_obs > 1 and bool((key_sorted[1:] == key_sorted[:-1]).any()):
         raise NotImplementedError("two stereo factors between the same pose and landmark are not supported")
@@ -28,7 +30,7 @@ def pack_observations(obs_pose, obs_point, meas, n_poses, n_points):
     point_ptr = torch.zeros(n_points + 1, dtype=torch.int64, device=dev)
     point_ptr[1:] = torch.cumsum(torch.bincount(ol, minlength=n_points), 0)
     # P-order: stable sort by pose keeps points ascending inside each pose
-    _, pobs_lidx = torch.sort(op, stable=True)
+    _, pobs_lidx = torch.sort(op.to(torch.int32) if n_poses < 2 ** 31 else op, stable=True)
     obs_ppos = torch.empty_like(pobs_lidx)
     obs_ppos[pobs_lidx] = torch.arange(n_obs, device=dev)
     pose_ptr = torch.zeros(n_poses + 1, dtype=torch.int64, device=dev)
