@@ -270,7 +270,8 @@ int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lamb
 int vus_ba_add_diag(double* Sband, int n_poses, int band, double value, void* stream);
 
 /* Solve S dp = -gs by block-band Cholesky; n_poses counts NODES.  Sband is overwritten by the factor L in
- * the solver's own layout: the 6x6 blocks left of the 8-node diagonal panels hold their transposes.
+ * the solver's own layout: the 6x6 blocks left of the 8-node diagonal panels hold their transposes, and (bands of
+ * 7 nodes and more) the diagonal panels themselves hold the INVERSE of their 48x48 factor block.
  * status[0] = 0 ok, k+1 = non-positive pivot met in scalar column k (dp is then undefined), -1 = the
  * cooperative back-substitution gave up waiting (never observed; the waits are bounded so that a scheduling
  * anomaly cannot hang the GPU).  The sweep's flags live in the unused slots of block row 0 of Sband.

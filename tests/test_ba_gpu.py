@@ -63,15 +63,24 @@ def test_kernels_match_oracle_stage_by_stage(gpu, oracle, size):
         assert status == 0 and int(sv.status.item()) == 0
         assert relerr(sv.dp.cpu().numpy(), dp) < 1e-8
         Lg = sv.Sband.cpu().numpy()
-        tril = np.tril(np.ones((6, 6), bool)).reshape(-1)
-        assert relerr(Lg[:, 0, tril], Lo[:, 0, tril]) < 1e-8          # diagonal blocks: lower part
+        nP, B = prob.n_poses, prob.band
         # blocks left of the 8-pose diagonal panels are stored transposed (read only by the back-substitution)
-        for i in range(1, prob.n_poses):
-            for sl in range(1, min(i, prob.band) + 1):
-                blk = Lg[i, sl].reshape(6, 6)
+        for i in range(1, nP):
+            for sl in range(1, min(i, B) + 1):
                 if i - sl < 8 * (i // 8):
-                    blk = blk.T
-                assert relerr(blk, Lo[i, sl].reshape(6, 6)) < 1e-7
+                    assert relerr(Lg[i, sl].reshape(6, 6).T, Lo[i, sl].reshape(6, 6)) < 1e-7
+        # the 8-pose diagonal panels hold the INVERSE of their factor block (inverted in place before the sweep) when
+        # the band reaches across a panel (>= 7 poses), else the factor itself
+        def panel(Lb, k0, pb):
+            M = np.zeros((6 * pb, 6 * pb))
+            for r in range(pb):
+                for c in range(max(0, r - B), r + 1):
+                    M[6 * r:6 * r + 6, 6 * c:6 * c + 6] = Lb[k0 + r, r - c].reshape(6, 6)
+            return np.tril(M)
+        for k0 in range(0, nP, 8):
+            pb = min(8, nP - k0)
+            Linv = panel(Lg, k0, pb)
+            assert relerr(np.linalg.inv(Linv) if B >= 7 else Linv, panel(Lo, k0, pb)) < 1e-7
         # back-substitution and step evaluation
         sv.backsub()
         sv.eval_step(poses, points)

@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(256, 4) void chol_syrk_kernel(BandSet S, int band, 
 //     result to y with f64 atomics.  Its operands are loaded one panel ahead of the x it waits for.
 // Flags (agent-scope atomics, see below): F[0] = panels solved, F[1] = abort, F[2 + g] = panels done by
 // workgroup g.  Every wait is bounded: a wait that expires raises the abort flag, all loops drain and
-// status = -1.  Only every 8th block of the grid works, which places all of them on one XCD (one L2).
+// status = -1.
 constexpr int BS_MAX_RHS = 8;
 constexpr int CB_THREADS = 512;          // 8 solver waves at most; threads < 8 * 48 = (panel row kk, output 6a + c)
 constexpr int CB_SPIN_LIMIT = 1 << 22;
@@ -1407,6 +1407,84 @@ __device__ __forceinline__ bool cb_wait(const int* f, int need, int* abort_flag)
   return false;
 }
 
+// The diagonal panels are INVERTED in place before the sweep (diag_invert_kernel: L_pp^-1 over L_pp, same block
+// layout, one wave per panel, all panels at once), so that the solver's x_p = L_pp^-T y' is 48 independent
+// multiply-adds per lane instead of a 48-step substitution with two v_readlane and one v_fma_f64 per dependent step
+// (instrumented: 3.7 k of the step's 12 k cycles, plus 2.9 k for fetching and scaling the strided column of L).
+// Slot t of the lower block triangle of a panel: block row r6, distance sd from the diagonal block, element e.
+constexpr int CB_DIAG_ELEMS = 36 * (PB * (PB + 1) / 2);
+constexpr int CB_DIAG_PER_LANE = (CB_DIAG_ELEMS + 63) / 64;
+__device__ __forceinline__ void cb_diag_slot(int t, int& r6, int& sd, int& e) {
+  r6 = 0;
+#pragma unroll
+  for (int q = 1; q < PB; ++q) r6 += t >= 36 * (q * (q + 1) / 2);
+  const int u = t - 36 * (r6 * (r6 + 1) / 2);
+  sd = u / 36;          // block (k0 + r6, k0 + r6 - sd)
+  e = u - 36 * sd;
+}
+
+__global__ __launch_bounds__(64) void diag_invert_kernel(BandSet S, int band, int n_solve) {
+  const int sysi = blockIdx.y, p = blockIdx.x, lane = threadIdx.x;
+  double* Sb = S.s[sysi].Sb;
+  const int n_poses = n_solve > 0 ? n_solve : S.s[sysi].n;
+  const int k0 = PB * p;
+  if (k0 >= n_poses) return;
+  const int nb = 6 * min(PB, n_poses - k0);
+  __shared__ double sL[NB * (NB + 1)];      // L_pp, dense, row stride NB + 1
+  __shared__ double sI[NB * (NB + 1)];      // its inverse
+  for (int t = lane; t < NB * (NB + 1); t += 64) {
+    sL[t] = 0.0;
+    sI[t] = 0.0;
+  }
+  __syncthreads();
+  const double* src[CB_DIAG_PER_LANE];
+  double v[CB_DIAG_PER_LANE];
+  unsigned have = 0;
+#pragma unroll
+  for (int j = 0; j < CB_DIAG_PER_LANE; ++j) {
+    const int t = lane + 64 * j;
+    int r6, sd, e;
+    cb_diag_slot(t < CB_DIAG_ELEMS ? t : 0, r6, sd, e);
+    const bool h = t < CB_DIAG_ELEMS && 6 * r6 < nb && sd <= band;
+    have |= (unsigned)h << j;
+    src[j] = h ? Sb + 36 * ((size_t)(k0 + r6) * (band + 1) + sd) + e : Sb;
+  }
+#pragma unroll
+  for (int j = 0; j < CB_DIAG_PER_LANE; ++j) v[j] = *src[j];
+#pragma unroll
+  for (int j = 0; j < CB_DIAG_PER_LANE; ++j) {
+    const int t = lane + 64 * j;
+    int r6, sd, e;
+    cb_diag_slot(t < CB_DIAG_ELEMS ? t : 0, r6, sd, e);
+    if ((have >> j) & 1) sL[(6 * r6 + e / 6) * (NB + 1) + 6 * (r6 - sd) + e % 6] = v[j];
+  }
+  __syncthreads();
+  __shared__ double sR[NB];                 // 1 / L_rr
+  if (lane < NB) sR[lane] = lane < nb ? 1.0 / sL[lane * (NB + 2)] : 0.0;
+  __syncthreads();
+  // lane j: column j of the inverse by forward substitution, x_r = (delta_rj - sum_{k<r} L_rk x_k) / L_rr
+  if (lane < nb) {
+    double x[NB];
+#pragma unroll
+    for (int r = 0; r < NB; ++r) {
+      double acc = r == lane ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) acc -= sL[r * (NB + 1) + k] * x[k];
+      x[r] = r >= lane ? acc * sR[r] : 0.0;
+      sI[r * (NB + 1) + lane] = x[r];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < CB_DIAG_PER_LANE; ++j) {
+    const int t = lane + 64 * j;
+    int r6, sd, e;
+    cb_diag_slot(t < CB_DIAG_ELEMS ? t : 0, r6, sd, e);
+    if ((have >> j) & 1)
+      Sb[36 * ((size_t)(k0 + r6) * (band + 1) + sd) + e] = sI[(6 * r6 + e / 6) * (NB + 1) + 6 * (r6 - sd) + e % 6];
+  }
+}
+
 // column `lane` of the diagonal block, pre-scaled: Lp[c] = L[c][lane] / L[lane][lane] for c > lane, else 0
 __device__ __forceinline__ void cb_load_diag(const double* __restrict__ Sb, int band, int k0, int nb, int lane,
                                              double (&Lp)[NB], double& dinv) {
@@ -1424,14 +1502,39 @@ __device__ __forceinline__ void cb_load_diag(const double* __restrict__ Sb, int 
   for (int c = 0; c < NB; ++c) Lp[c] *= dinv;
 }
 
-__global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, int band, int n_rhs, int n_groups, int n_solve) {
-  if (blockIdx.x & 7) return;
+// column `lane` of the inverted diagonal panel: Lp[r] = (L_pp^-1)[r][lane] for r >= lane, else 0.  (Only called
+// with band >= PB - 1: every block of the panel's lower triangle is stored.)  One per-lane base pointer, the rest
+// of every address is the same for all lanes.
+__device__ __forceinline__ void cb_load_inv(const double* __restrict__ Sb, int band, int k0, int nb, int lane,
+                                            double (&Lp)[NB]) {
+  const int ln = lane < NB ? lane : 0;
+  const int c6 = ln / 6, cm = ln - 6 * c6;
+  const double* col = Sb + 36 * (size_t)k0 * (band + 1) + (cm - 36 * c6);    // element (row 0 of the panel, column ln)
+  const int stride = 36 * (band + 2);                                         // one block row down, same block column
+  // entries above the diagonal (and rows >= nb of a short last panel) are not stored: those lanes read the panel's
+  // first element instead.  All 48 loads are issued before the first result is looked at.
+  const double* safe = Sb + 36 * (size_t)k0 * (band + 1);
+#pragma unroll
+  for (int r = 0; r < NB; ++r) {
+    const double* src = (r < nb && lane <= r) ? col + ((r / 6) * stride + 6 * (r % 6)) : safe;
+    Lp[r] = *src;
+  }
+#pragma unroll
+  for (int r = 0; r < NB; ++r)
+    if (!(r < nb && lane <= r)) Lp[r] = 0.0;
+}
+
+__global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, int band, int n_rhs, int n_groups, int n_solve,
+                                                                   int inverted) {
   // workgroup index g inside its system: 0 = solver, w >= 1 serves row groups w, w + n_wg - 1, ...; with two systems
-  // (the two halves of the two-sided solve) consecutive working blocks alternate between them
-  const int wg = blockIdx.x >> 3;
+  // (the two halves of the two-sided solve) consecutive blocks alternate between them.  The workgroups spread over
+  // all XCDs: everything they exchange goes through agent-scope atomics, i.e. through the memory side, whether or not
+  // they share an L2, and ONE XCD holds 24 of these 512-thread blocks -- fewer than configs[2] has row groups, which
+  // gave every helper two or three groups per panel and made the helpers the pace of the sweep.
+  const int wg = blockIdx.x;
   const int sysi = S.count == 2 ? (wg & 1) : 0;
   const int g = S.count == 2 ? (wg >> 1) : wg;
-  const int n_helpers = (int)(gridDim.x >> 3) / S.count - 1;
+  const int n_helpers = (int)gridDim.x / S.count - 1;
   const double* __restrict__ Sb = S.s[sysi].Sb;
   double* yv = S.s[sysi].y;
   int* F = S.s[sysi].F;
@@ -1442,7 +1545,6 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
   const size_t ystride = 6 * (size_t)S.s[sysi].n;
   __shared__ double s_x[BS_MAX_RHS][NB];
   __shared__ double s_part[BS_MAX_RHS][PB][NB];
-  __shared__ double s_own[BS_MAX_RHS][NB];
   __shared__ int s_go;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NP = (n_poses + PB - 1) / PB;
@@ -1473,7 +1575,8 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
     double dinv = 1.0;
     if (wave < n_rhs) {
       const int k0 = PB * (NP - 1);
-      cb_load_diag(Sb, band, k0, 6 * min(PB, n_poses - k0), lane, Lp, dinv);
+      if (inverted) cb_load_inv(Sb, band, k0, 6 * min(PB, n_poses - k0), lane, Lp);
+      else cb_load_diag(Sb, band, k0, 6 * min(PB, n_poses - k0), lane, Lp, dinv);
     }
     for (int s = 0; s < NP; ++s) {
       const int p = NP - 1 - s, k0 = PB * p;
@@ -1493,11 +1596,21 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         double* yq = yv + (size_t)wave * ystride;
         double yr = lane < nb ? __hip_atomic_load(&yq[6 * k0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        if (s > 0 && lane < NB) yr -= s_own[wave][lane];
-        double z = yr * dinv;           // z_r = y_r / L_rr;  x_c = z_c once every column > c is applied
+        if (s > 0 && lane < NB) {       // what x of the panel below added (its eight block rows' products)
 #pragma unroll
-        for (int cc = NB - 1; cc >= 0; --cc)
-          if (cc < nb) z -= Lp[cc] * bcast_lane(z, cc);
+          for (int k2 = 0; k2 < PB; ++k2) yr -= s_part[wave][k2][lane];
+        }
+        double z;
+        if (inverted) {                 // x_c = sum_r (L_pp^-1)[r][c] y'_r: independent multiply-adds
+          z = 0.0;
+#pragma unroll
+          for (int r = 0; r < NB; ++r) z += Lp[r] * bcast_lane(yr, r);
+        } else {                        // narrow bands: substitution.  z_r = y_r / L_rr;  x_c = z_c once every column > c is applied
+          z = yr * dinv;
+#pragma unroll
+          for (int cc = NB - 1; cc >= 0; --cc)
+            if (cc < nb) z -= Lp[cc] * bcast_lane(z, cc);
+        }
         if (lane < nb) {
           __hip_atomic_store(&yq[6 * k0 + lane], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           s_x[wave][lane] = z;
@@ -1510,15 +1623,10 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
       if (tid == 0) __hip_atomic_store(F, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (p > 0) {   // contribution of x_p to the panel right above (kept in LDS, subtracted at the next step)
         CB_PARTIAL_DOTS();
-        __syncthreads();
-        if (tid < NB * n_rhs) {
-          const int q = tid / NB, r = tid - NB * q;
-          double sum = 0.0;
-#pragma unroll
-          for (int k2 = 0; k2 < PB; ++k2) sum += s_part[q][k2][r];
-          s_own[q][r] = sum;
+        if (wave < n_rhs) {
+          if (inverted) cb_load_inv(Sb, band, k0 - PB, NB, lane, Lp);
+          else cb_load_diag(Sb, band, k0 - PB, NB, lane, Lp, dinv);
         }
-        if (wave < n_rhs) cb_load_diag(Sb, band, k0 - PB, NB, lane, Lp, dinv);
         CB_LOAD_ROWS(p - 1);
       }
       __syncthreads();
@@ -1527,7 +1635,7 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
     // ---- row group gg: panels NP-1 .. gg+1 contribute to panels NP-gg-2 .. 0 ----
     // Normally one row group per workgroup (its block rows prefetched one panel ahead).  Bands wider than
     // 8 * n_helpers poses give a workgroup several groups (gg = g, g + n_helpers, ...): all active workgroups
-    // must be co-resident on one XCD for the flag protocol to make progress, so their number is capped.
+    // must be resident at once for the flag protocol to make progress, so their number is capped.
     const bool single = g + n_helpers >= n_groups;
     for (int s = 0; s < NP - g - 1; ++s) {
       const int p = NP - 1 - s, k0 = PB * p;
@@ -1805,10 +1913,11 @@ int* flags_fallback() {
   return buf[dev];
 }
 
-// Number of workgroups of the cooperative back-substitution that are guaranteed to be co-resident even if the
-// dispatcher puts every working block (blockIdx % 8 == 0) on ONE XCD: the occupancy query for this kernel times
-// the compute units of one XCD, less a margin of one workgroup per four CUs (the query can read one block per
-// CU high, MI355X_MICROARCH.md "Residency and cooperative launch").  VUS_CB_MAX_WG (compile time) and the
+// Number of workgroups of the cooperative back-substitution that can be resident at once: the occupancy query for
+// this kernel times the compute units of the device, less a margin of one workgroup per eight CUs (the query can
+// read one block per CU high, MI355X_MICROARCH.md "Residency and cooperative launch").  The waits are bounded, so a
+// workgroup that is not resident after all (another stream holding CUs) ends in status -1, not in a hang.
+// VUS_CB_MAX_WG (compile time) and the
 // environment variable of the same name (run time, used by the tests to force several row groups per
 // workgroup) cap it further.
 int backsolve_max_wg() {
@@ -1823,8 +1932,7 @@ int backsolve_max_wg() {
       int per_cu = 0, n_cu = 0;
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_backsolve_kernel, CB_THREADS, 0) != hipSuccess) per_cu = 1;
       if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n_cu = 8;
-      const int cu_xcd = n_cu >= 8 ? n_cu / 8 : 1;
-      int c = per_cu * cu_xcd - cu_xcd / 4;
+      int c = per_cu * n_cu - n_cu / 8;      // all of them must be resident at once: leave a margin
       cached[dev] = c < 1 ? 1 : c;
     }
     cap = cached[dev];
@@ -1925,7 +2033,21 @@ SplitAux* split_aux() {
 }
 
 // Cooperative back-substitution x = L^-T y of every system of S (n_solve > 0: of its leading n_solve poses only).
-int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st) {
+// The diagonal panels of every system of S inverted in place (see diag_invert_kernel); false = band too narrow
+bool diag_invert_launch(const BandSet& S, int band, int n_solve, hipStream_t st) {
+  // The inverse of a diagonal panel is a full lower triangle: it fits the panel's own storage only if the band
+  // reaches across the panel (band >= 7 poses); narrower bands keep the factor and substitute.
+  if (band < PB - 1) return false;
+  int np_max = 0;
+  for (int q = 0; q < S.count; ++q) {
+    const int n_q = n_solve > 0 ? n_solve : S.s[q].n;
+    np_max = (n_q + PB - 1) / PB > np_max ? (n_q + PB - 1) / PB : np_max;
+  }
+  diag_invert_kernel<<<dim3(np_max, S.count), 64, 0, st>>>(S, band, n_solve);
+  return true;
+}
+
+int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st, bool pre_inverted = false) {
   // flags of the cooperative sweep live in the unused slots of block row 0 (blocks (0, k < 0))
   const int n_groups = band > 0 ? (band + PB - 1) / PB : 1;
   VUS_REQUIRE(band == 0 || 2 + n_groups <= 72 * band, "band=%d: too many row groups for the flag area", band);
@@ -1935,11 +2057,12 @@ int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st
     VUS_REQUIRE(band > 0 || S.count == 1, "two band-0 systems cannot share the fallback flags");
     VUS_CHECK_HIP(hipMemsetAsync(S.s[q].F, 0, sizeof(int) * (size_t)(2 + n_groups), st));
   }
+  const int inverted = pre_inverted ? 1 : (int)diag_invert_launch(S, band, n_solve, st);
   // at most backsolve_max_wg() cooperating workgroups in total, so that all of them are resident at once
   int max_wg = backsolve_max_wg() / S.count;
   if (max_wg < 2) max_wg = 2;       // a solver and at least one helper per system (the helper then serves every row group)
   const int n_wg = n_groups < max_wg ? n_groups : max_wg;
-  chol_backsolve_kernel<<<8 * n_wg * S.count, CB_THREADS, 0, st>>>(S, band, n_rhs, n_groups, n_solve);
+  chol_backsolve_kernel<<<n_wg * S.count, CB_THREADS, 0, st>>>(S, band, n_rhs, n_groups, n_solve, inverted);
   VUS_CHECK_LAUNCH("ba_band_backsolve");
   return VUS_OK;
 }
@@ -2126,6 +2249,7 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
   S.count = 2;
   S.s[0] = BandSys{Sband, yT, status, nullptr, p.nT};
   S.s[1] = BandSys{Rb, yR, st_R, nullptr, p.nT};
+  SplitAux* aux2 = nullptr;
   {
     // the halves are independent chains until the middle system: the pose-reversed one runs on a second stream
     SplitAux* aux = nullptr;
@@ -2140,13 +2264,23 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
       VUS_CHECK_HIP(hipEventRecord(aux->join, aux->s2));
       VUS_CHECK_HIP(hipStreamWaitEvent(st, aux->join, 0));
     }
+    aux2 = aux;
+  }
+  // the diagonal panels of both halves are inverted (for their back-substitution) beside the middle system's solve
+  bool halves_inverted = false;
+  if (aux2) {
+    VUS_CHECK_HIP(hipEventRecord(aux2->fork, st));
+    VUS_CHECK_HIP(hipStreamWaitEvent(aux2->s2, aux2->fork, 0));
+    halves_inverted = diag_invert_launch(S, band, p.m, aux2->s2);
+    VUS_CHECK_HIP(hipEventRecord(aux2->join, aux2->s2));
   }
   const size_t nM = 36 * (size_t)p.n_mid * (p.bm + 1);
   split_mid_kernel<<<cdiv((long long)nM, 256), 256, 0, st>>>(Sband, y, p, Rb, yT, yR, Mid, yM);
   if (int rc = band_solve_impl(Mid, p.n_mid, p.bm, yM, n_rhs, st_M, st)) return rc;
   const int n_spike = band < p.m ? band : p.m;
   split_spike_kernel<<<dim3(n_spike, 2, n_rhs), 64, 0, st>>>(Sband, Rb, p, yM, yT, yR);
-  if (int rc = backsolve_launch(S, band, n_rhs, p.m, st)) return rc;     // the eliminated poses of both halves
+  if (aux2) VUS_CHECK_HIP(hipStreamWaitEvent(st, aux2->join, 0));
+  if (int rc = backsolve_launch(S, band, n_rhs, p.m, st, halves_inverted)) return rc;     // the eliminated poses of both halves
   split_gather_kernel<<<cdiv(6ll * n * n_rhs, 256), 256, 0, st>>>(p, yT, yR, yM, y, st_R, st_M, status);
   VUS_CHECK_LAUNCH("ba_band_solve_split");
   return VUS_OK;
