@@ -1329,6 +1329,25 @@ __global__ __launch_bounds__(256, 4) void chol_syrk_kernel(BandSet S, int band, 
   }
   __syncthreads();
   const bool crit = bid == 0 && factor_next;
+  // Two passes: all new values first, then the stores back to back.  In one loop every store was preceded by an
+  // s_waitcnt vmcnt(0) (for the old value it combines), which on this in-order counter also waits for the PREVIOUS
+  // store to be acknowledged: five serialised round trips per thread, on the critical tile too.  The explicit wait
+  // tells the compiler that the old values (loaded under per-vector conditions long ago) have all arrived.
+  __builtin_amdgcn_s_waitcnt(0x0F70);    // vmcnt(0)
+#pragma unroll
+  for (int u = 0; u < CV; ++u) {
+    if (!vmask[u]) continue;
+    const int v = tid + 256 * u;
+    const int ii = v / 144, w = v - 144 * ii;
+    const int o = w / 18, e = 2 * (w - 18 * o);
+    const int rr = e / 6, c = e - 6 * rr;
+    double* d = Xj + (6 * ii + rr) * LDD + 6 * (7 - o) + c;
+    d2a_t nv = oldv[u];
+    if (vmask[u] & 1u) nv.x -= d[0];
+    if (vmask[u] & 2u) nv.y -= d[1];
+    oldv[u] = nv;
+    if (crit) { d[0] = nv.x; d[1] = nv.y; }      // tile (0,0): the updated block stays in LDS for the factorisation
+  }
 #pragma unroll
   for (int u = 0; u < CV; ++u) {
     if (!vmask[u]) continue;
@@ -1336,13 +1355,7 @@ __global__ __launch_bounds__(256, 4) void chol_syrk_kernel(BandSet S, int band, 
     const int ii = v / 144, w = v - 144 * ii;
     const int o = w / 18, e = 2 * (w - 18 * o);
     const int i = pi0 + ii, j = pj0 + 7 - o;
-    const int rr = e / 6, c = e - 6 * rr;
-    double* d = Xj + (6 * ii + rr) * LDD + 6 * (7 - o) + c;
-    d2a_t nv = oldv[u];
-    if (vmask[u] & 1u) nv.x -= d[0];
-    if (vmask[u] & 2u) nv.y -= d[1];
-    *reinterpret_cast<d2a_t*>(Sb + 36 * ((long long)i * (band + 1) + (i - j)) + e) = nv;
-    if (crit) { d[0] = nv.x; d[1] = nv.y; }      // tile (0,0): the updated block stays in LDS for the factorisation
+    *reinterpret_cast<d2a_t*>(Sb + 36 * ((long long)i * (band + 1) + (i - j)) + e) = oldv[u];
   }
   if (crit) {
     // Tile (0,0) is the next panel's diagonal block, complete once this workgroup has stored it: factor it here.
