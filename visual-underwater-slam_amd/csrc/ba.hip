@@ -1558,7 +1558,8 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
   const size_t ystride = 6 * (size_t)S.s[sysi].n;
   __shared__ double s_x[BS_MAX_RHS][NB];
   __shared__ double s_part[BS_MAX_RHS][PB][NB];
-  __shared__ int s_go;
+  __shared__ double s_y[2][BS_MAX_RHS][NB];       // solver: y of this panel / of the next one (look-ahead wave)
+  __shared__ int s_go, s_go2[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NP = (n_poses + PB - 1) / PB;
   const int kk = tid / NB, oc = tid - NB * kk;    // update task: panel row kk, output oc = 6a + c
@@ -1591,24 +1592,28 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
       if (inverted) cb_load_inv(Sb, band, k0, 6 * min(PB, n_poses - k0), lane, Lp);
       else cb_load_diag(Sb, band, k0, 6 * min(PB, n_poses - k0), lane, Lp, dinv);
     }
+    // Two of the step's round trips to the coherence point are taken off its chain: while the solving waves work on
+    // panel p, the last wave (idle otherwise: the products use threads < 8 * 48) waits for the flags of every
+    // workgroup that adds to y of panel p-1 and loads that y into LDS.  (Those flags only depend on x of panels
+    // published in EARLIER steps, so the wait cannot depend on this step's own flag.)
+    constexpr int LA = CB_THREADS / 64 - 1;
+    if (wave == LA) {              // y of the last panel: nobody adds to it
+      const int k0 = PB * (NP - 1), nb = 6 * min(PB, n_poses - k0);
+      for (int t = lane; t < NB * n_rhs; t += 64) {
+        const int q = t / NB, r = t - NB * q;
+        s_y[0][q][r] = r < nb ? __hip_atomic_load(&yv[(size_t)q * ystride + 6 * k0 + r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+      }
+      if (lane == 0) s_go2[0] = 1;
+    }
+    __syncthreads();
     for (int s = 0; s < NP; ++s) {
       const int p = NP - 1 - s, k0 = PB * p;
       const int nb = 6 * min(PB, n_poses - k0);
-      if (wave == 0) {   // every workgroup that adds to y_p must have finished the panel it comes from
-        bool ok = true;
-        for (int g0 = 1; g0 < n_groups && ok; g0 += 64) {
-          const int gg = g0 + lane;
-          if (gg < n_groups && s - gg > 0) ok = cb_wait(F + 2 + gg, s - gg, abort_flag);
-          ok = __all(ok);
-        }
-        if (lane == 0) s_go = ok;
-      }
-      __syncthreads();
-      if (!s_go) break;
+      const int cur = s & 1;
+      if (!s_go2[cur]) break;
       if (wave < n_rhs) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         double* yq = yv + (size_t)wave * ystride;
-        double yr = lane < nb ? __hip_atomic_load(&yq[6 * k0 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        double yr = lane < NB ? s_y[cur][wave][lane] : 0.0;
         if (s > 0 && lane < NB) {       // what x of the panel below added (its eight block rows' products)
 #pragma unroll
           for (int k2 = 0; k2 < PB; ++k2) yr -= s_part[wave][k2][lane];
@@ -1631,6 +1636,23 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
           s_x[wave][lane] = 0.0;
         }
         cb_drain();
+      }
+      if (wave == LA && p > 0) {   // look-ahead (after its own solve when all eight waves carry a right-hand side)
+        bool ok = true;
+        for (int g0 = 1; g0 < n_groups && ok; g0 += 64) {
+          const int gg = g0 + lane;
+          if (gg < n_groups && s + 1 - gg > 0) ok = cb_wait(F + 2 + gg, s + 1 - gg, abort_flag);
+          ok = __all(ok);
+        }
+        if (ok) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          for (int t = lane; t < NB * n_rhs; t += 64) {     // a full panel: NB rows
+            const int q = t / NB, r = t - NB * q;
+            s_y[cur ^ 1][q][r] = __hip_atomic_load(&yv[(size_t)q * ystride + 6 * (k0 - PB) + r], __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (lane == 0) s_go2[cur ^ 1] = ok;
       }
       __syncthreads();
       if (tid == 0) __hip_atomic_store(F, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
