@@ -7,8 +7,8 @@
 // and error evaluation.  The Levenberg-Marquardt control flow stays on the host (ba.py).
 //
 // Layout (include/vus.h): observations in L-order (point-major) and P-order (pose-major) with both
-// permutations precomputed; per-observation 6x3 products W, Y in P-order so that every block of the
-// reduced camera system reads two compact per-pose segments.
+// permutations precomputed; the per-observation 6x3 product W in P-order so that every block of the
+// reduced camera system reads two compact per-pose segments (Y = W Vinv is formed on the fly).
 //
 // Kernel map.  Reductions are fixed-order wave / LDS / DPP sums everywhere except the cooperative
 // back-substitution of the band solve, which adds its partial products into the right-hand side with f64
@@ -17,13 +17,15 @@
 //   lin_points   wave / point      r, H1, H2 -> W (scatter to P-order), V, gl, error partial
 //   lin_poses    workgroup / pose  r, H1 (recomputed, never stored) -> Hpp, gp
 //   priors       one lane          PriorFactorPose3 information / gradient / error
-//   vinv, ymul   thread / point, thread / obs   (V + lambda I)^-1,  Y = W Vinv
-//   schur_init / schur_rows / schur_rhs   S = Hpp + lambda I - sum Y W^T (one workgroup per block row, the
-//                row's Y resident in LDS, W rows gathered per co-observation pair), gs = gp - sum Y gl
-//                (schur_mfma: the same contraction on v_mfma_f64_4x4x4, kept as the measured alternative)
-//   chol_panel (panel 0) / chol_trsm_update (one launch per 8-pose panel: MFMA block substitution of the two
-//                row tiles a 48x48 update tile needs, SYRK on v_mfma_f64_16x16x4_f64, tile (0,0) goes on
-//                to factor the next panel) / chol_backsolve (cooperative, flag-ordered)
+//   vinv (ymul)  thread / point, thread / obs   (V + lambda I)^-1  (Y = W Vinv only as an optional output)
+//   schur_init / schur_rows / schur_rhs   S = Hpp + lambda I - sum Y W^T (persistent workgroups, one block row at
+//                a time: the row's Y = W Vinv formed into LDS, W rows gathered per co-observation pair from the
+//                pair lists of structure.hip), gs = gp - sum W (Vinv gl)
+//   chol_panel (panel 0) / chol_trsm + chol_syrk (two launches per 8-pose panel: MFMA block substitution of the
+//                window's row tiles, then the SYRK tiles on v_mfma_f64_16x16x4_f64, tile (0,0) goes on to factor
+//                the next panel; chol_trsm_update = both fused in one launch, used for a single system) /
+//                diag_invert + chol_backsolve (diagonal panels inverted in place, then the cooperative,
+//                flag-ordered sweep) / split_* (two-sided elimination: both ends of the band at once)
 //   backsub      wave / point      dl = -Vinv (gl + sum W^T dp)
 //   retract, eval_points, error_points, reduce_partials
 #include <cstdlib>
@@ -1377,10 +1379,11 @@ __global__ __launch_bounds__(256, 4) void chol_syrk_kernel(BandSet S, int band, 
 // One compute unit cannot stream the factor fast enough (a single CU sustains ~35 GB/s from HBM, the
 // factor of a 2000-pose / band-224 problem is 130 MB), so the sweep is spread over one workgroup per
 // 8-pose row group of the band:
-//   workgroup 0 (the solver) owns the sequential part: per panel p (last to first) it waits until the
-//     contributions to y_p have arrived, solves the 48x48 diagonal block (lane = row, the lane's
-//     pre-scaled column of L in registers, x broadcast with readlane: two dependent instructions per
-//     column), publishes x_p, and computes the contribution of x_p to the panel right above itself;
+//   workgroup 0 (the solver) owns the sequential part: per panel p (last to first) it takes y_p once the
+//     contributions to it have arrived (awaited and loaded one panel ahead by its eighth wave), multiplies it
+//     with the inverted 48x48 diagonal block (lane = row, the lane's column of L_pp^-1 in registers; bands
+//     narrower than a panel: substitution with the pre-scaled column of L_pp instead), publishes x_p, and
+//     computes the contribution of x_p to the panel right above itself;
 //   workgroup g >= 1 waits for x_p, multiplies it with the blocks L(panel p, panel p - g - 1)^T --
 //     transposed on write-back, so an output reads one contiguous 48-byte block row -- and adds the
 //     result to y with f64 atomics.  Its operands are loaded one panel ahead of the x it waits for.
