@@ -298,6 +298,22 @@ int vus_ba_band_solve_split(double* Sband, int n_poses, int band, const double* 
 int vus_ba_band_solve_multi_split(double* Sband, int n_nodes, int band, double* rhs, int n_rhs, int* status,
                                   double* work, void* stream);
 
+/* Thread safety of the two-sided solves: re-entrant.  Each call forks onto an auxiliary stream and a fork/join event
+ * pair that belong to (device, caller's stream); two host threads solving on different streams of one device share
+ * nothing, two calls on the SAME stream are ordered by that stream as usual.  Whatever the call returns, the caller's
+ * stream has been made to wait for every launch the call issued on the auxiliary stream.
+ *
+ * Tuning knobs of the band solve (tests and A/B timing; the defaults are right for production).  Their initial values
+ * are read from the environment ONCE, when the library is loaded (VUS_BAND_MODE, VUS_CB_MAX_WG); afterwards only
+ * vus_ba_set_tuning() changes them, process-wide.  Host-only calls, no device work.
+ *   VUS_TUNE_BAND_MODE   how a panel step is issued: -1 automatic; 0 one fused launch per panel; 1 a TRSM + SYRK launch
+ *                        pair per panel (two systems share every launch); 2 the same pair per system on two streams.
+ *   VUS_TUNE_CB_MAX_WG   cap on the cooperating workgroups of the back-substitution (0 = from the occupancy query). */
+#define VUS_TUNE_BAND_MODE 0
+#define VUS_TUNE_CB_MAX_WG 1
+int vus_ba_set_tuning(int knob, int value);
+int vus_ba_get_tuning(int knob);
+
 /* ---- navigation factors on the camera side (graphs with vus_nav_factors, pose_stride = 2) ----
  * vus_nav_linearize: residuals/Jacobians of every ImuFactor / DVL factor / velocity prior at
  * (poses, vels, bias), accumulated (camera-side blocks with f64 atomics -- at most four addends per block, so two runs

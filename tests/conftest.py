@@ -37,3 +37,20 @@ def same_lm_trajectory(iterations, outer, tries, status, err_hist, orep):
         h = list(err_hist)
         assert abs(iterations - orep["iterations"]) == 1 and len(h) >= 2 and abs(h[-1] - h[-2]) <= 1e-12 * abs(h[-1]), \
             (iterations, orep["iterations"], h[-3:])
+
+
+@pytest.fixture
+def band_tuning():
+    """Set the band solve's tuning knobs for one test (vus_ba_set_tuning) and restore them afterwards."""
+    from visual_underwater_slam_amd import _lib
+    lib = _lib.load()
+    before = {k: lib.vus_ba_get_tuning(k) for k in (_lib.TUNE_BAND_MODE, _lib.TUNE_CB_MAX_WG)}
+
+    def set_(band_mode=None, cb_max_wg=None):
+        if band_mode is not None:
+            _lib.call("vus_ba_set_tuning", _lib.TUNE_BAND_MODE, int(band_mode))
+        if cb_max_wg is not None:
+            _lib.call("vus_ba_set_tuning", _lib.TUNE_CB_MAX_WG, int(cb_max_wg))
+    yield set_
+    for k, v in before.items():
+        _lib.call("vus_ba_set_tuning", k, v)

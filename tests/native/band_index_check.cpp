@@ -1,0 +1,148 @@
+// CPU sweep of visual-underwater-slam_amd/csrc/band_index.h: the address arithmetic of the band-solve kernels, run for
+// every (panel, thread) of a system of n poses and half-bandwidth `band` exactly as factor_launches() / backsolve_launch()
+// of ba.hip launch them, against a REAL buffer of the band's size (built with -fsanitize=address,undefined by
+// tests/test_band_index.py: an offset outside the buffer is an ASan report, not only a failed comparison).
+// Test infrastructure; not part of the product.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../../visual-underwater-slam_amd/csrc/band_index.h"
+
+namespace {
+using namespace bandidx;
+
+struct Sweep {
+  int n, band;
+  long long total;
+  std::vector<double> buf;
+  long long touched = 0, bad = 0;
+  char first[256] = {0};
+  double sink = 0;
+
+  void fail(const char* what, long long off, int width, int a, int b, int c) {
+    if (!bad) snprintf(first, sizeof first, "%s: offset %lld (+%d) outside [0, %lld) at (%d, %d, %d), n=%d band=%d", what, off, width, total, a, b, c, n, band);
+    ++bad;
+  }
+  // `off` (if not masked) must address `width` doubles inside the band; they are really read
+  void touch(const char* what, long long off, int width, int a = 0, int b = 0, int c = 0) {
+    if (off < 0) {
+      if (off != -1) fail(what, off, width, a, b, c);
+      return;
+    }
+    if (off + width > total) { fail(what, off, width, a, b, c); return; }
+    for (int k = 0; k < width; ++k) sink += buf[(size_t)off + k];
+    ++touched;
+  }
+  void expect(const char* what, long long got, long long want, int a, int b, int c) {
+    if (got >= 0 && got != want) {
+      if (!bad) snprintf(first, sizeof first, "%s: offset %lld, expected %lld at (%d, %d, %d), n=%d band=%d", what, got, want, a, b, c, n, band);
+      ++bad;
+    }
+  }
+};
+
+void sweep_factor(Sweep& S, int n_elim) {
+  const int n = S.n, band = S.band;
+  for (int k0 = 0; k0 < n_elim; k0 += PB) {
+    const int pb = n - k0 < PB ? n - k0 : PB, nb = 6 * pb;
+    const int i_first = k0 + pb;
+    int i_last = k0 + pb - 1 + band;
+    if (i_last > n - 1) i_last = n - 1;
+    const int rows = i_last - i_first + 1;
+    const int tiles = rows > 0 ? (rows + UTP - 1) / UTP : 0;
+    for (int R = 0; R < 64; ++R)
+      for (int kb = 0; kb < 8; ++kb) {
+        const long long o = panel_row(band, k0, nb, R, kb);
+        S.touch("panel_row", o, 6, k0, R, kb);
+        S.expect("panel_row", o, blk(band, k0 + R / 6, k0 + kb) + 6 * (R % 6), k0, R, kb);
+      }
+    constexpr int ITEMS = 6 * UTP * PB;
+    const int n_items = ((3 * ITEMS + 255) / 256) * 256;
+    for (int t = 0; t < tiles; ++t) {
+      const int p0 = i_first + t * UTP;
+      for (int item = 0; item < n_items; ++item) S.touch("stage_item/trsm", stage_item(band, k0, pb, i_last, p0, p0, 1, item), 6, k0, t, item);
+      for (int e = 0; e < UTP * PB * 6; ++e) {
+        const long long o = solved_item(band, k0, pb, i_last, p0, e);
+        S.touch("solved_item", o, 6, k0, t, e);
+        const int ii = e / 48, kk = (e % 48) / 6, c = e % 6;
+        S.expect("solved_item", o, blk(band, p0 + ii, k0 + kk) + 6 * c, k0, t, e);
+      }
+    }
+    for (int ti = 0; ti < tiles; ++ti)
+      for (int tj = 0; tj <= ti; ++tj) {
+        const int pi0 = i_first + ti * UTP, pj0 = i_first + tj * UTP;
+        for (int item = 0; item < n_items; ++item)
+          S.touch("stage_item/update", stage_item(band, k0, pb, i_last, pi0, pj0, ti == tj ? 1 : 2, item), 6, k0, ti * 1000 + tj, item);
+        for (int v = 0; v < 5 * 256; ++v) {
+          unsigned m;
+          const long long o = tile_vec(band, i_last, pi0, pj0, v, m);
+          S.touch("tile_vec", o, 2, k0, ti * 1000 + tj, v);
+          if (o >= 0) {
+            const int ii = v / 144, w = v % 144, ob = w / 18, e = 2 * (w % 18);
+            S.expect("tile_vec", o, blk(band, pi0 + ii, pj0 + 7 - ob) + e, k0, ti * 1000 + tj, v);
+            if (pj0 + 7 - ob > pi0 + ii || pi0 + ii - (pj0 + 7 - ob) > band) S.fail("tile_vec: block outside the band", o, 2, k0, ti * 1000 + tj, v);
+          }
+        }
+        for (int Rr = 0; Rr < 48; ++Rr)
+          for (int Cc = 0; Cc < 48; ++Cc) S.touch("tile_scalar", tile_scalar(band, i_last, pi0, pj0, Rr, Cc), 1, k0, Rr, Cc);
+      }
+  }
+}
+
+void sweep_backsolve(Sweep& S, int n_solve) {
+  const int band = S.band;
+  const int n_poses = n_solve > 0 ? n_solve : S.n;
+  const int NP = (n_poses + PB - 1) / PB;
+  const int n_groups = band > 0 ? (band + PB - 1) / PB : 1;
+  for (int p = 0; p < NP; ++p) {
+    const int k0 = PB * p, nb = 6 * (n_poses - k0 < PB ? n_poses - k0 : PB);
+    for (int t = 0; t < ((DIAG_ELEMS + 63) / 64) * 64; ++t) S.touch("diag_elem", diag_elem(band, k0, nb, t), 1, k0, t);
+    for (int lane = 0; lane < 64; ++lane) {
+      S.touch("cb_diag_pivot", cb_diag_pivot(band, k0, nb, lane), 1, k0, lane);
+      for (int c = 0; c < NB; ++c) {
+        S.touch("cb_diag", cb_diag(band, k0, nb, lane, c), 1, k0, lane, c);
+        if (band >= PB - 1) {
+          const long long o = cb_inv(band, k0, nb, lane, c);
+          S.touch("cb_inv", o, 1, k0, lane, c);
+          S.expect("cb_inv", o, blk(band, k0 + c / 6, k0 + lane / 6) + 6 * (c % 6) + lane % 6, k0, lane, c);
+        }
+      }
+    }
+    if (band >= PB - 1) S.touch("cb_inv_safe", cb_inv_safe(band, k0), 1, k0);
+    for (int g = 0; g < n_groups; ++g)
+      for (int tid = 0; tid < 512; ++tid) {
+        const int kk = tid / NB, oc = tid - NB * kk, a = oc / 6, c = oc - 6 * a;
+        S.touch("cb_rows", cb_rows(band, n_poses, p, g, kk, a, c), 6, p, g, tid);
+      }
+  }
+}
+}  // namespace
+
+// Returns the number of offsets that fell outside the band of (n, band) [0 = all good]; `touched` receives the number of
+// in-range accesses made, `msg` (256 bytes) the first violation.  n_elim: poses eliminated (n = whole matrix).
+extern "C" long long bandidx_sweep(int n, int band, int n_elim, long long* touched, char* msg) {
+  Sweep S;
+  S.n = n;
+  S.band = band;
+  S.total = band_doubles(n, band);
+  S.buf.assign((size_t)S.total, 1.0);
+  sweep_factor(S, n_elim);
+  sweep_backsolve(S, n_elim < n ? n_elim : 0);
+  if (touched) *touched = S.touched + (S.sink < 0 ? 1 : 0);
+  if (msg) snprintf(msg, 256, "%s", S.first);
+  return S.bad;
+}
+
+// The checker checking itself: round 2's faulting address (cb_load_inv's per-lane column base used WITHOUT the
+// masked-lane guard, first panel, last lane) must be counted as a violation.
+extern "C" long long bandidx_selftest_unguarded(int n, int band, char* msg) {
+  Sweep S;
+  S.n = n;
+  S.band = band;
+  S.total = band_doubles(n, band);
+  const int lane = NB - 1, c6 = lane / 6, cm = lane - 6 * c6;
+  const long long col = 36ll * 0 * (band + 1) + (cm - 36 * c6);       // row 0 of panel 0, column `lane`: above the diagonal
+  S.touch("unguarded cb_load_inv", col == -1 ? -2 : col, 1, 0, lane, 0);
+  if (msg) snprintf(msg, 256, "%s", S.first);
+  return S.bad;
+}

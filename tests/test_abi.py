@@ -4,6 +4,9 @@ import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+# entry points that return something else than a status code (bound by hand in _lib.load) or have no device work
+HOST_ONLY = ("vus_abi_version", "vus_last_error", "vus_ba_work_doubles", "vus_nav_work_doubles",
+             "vus_ba_band_solve_work_doubles", "vus_ba_get_tuning")
 
 
 def _declared():
@@ -28,14 +31,14 @@ def test_hip_library_exports_every_declared_symbol():
     # the python binding covers every declared compute entry point
     L.load()
     for name in _declared():
-        if name not in ("vus_abi_version", "vus_last_error", "vus_ba_work_doubles", "vus_nav_work_doubles", "vus_ba_band_solve_work_doubles"):
+        if name not in HOST_ONLY:
             assert name in L.SIGNATURES, f"{name} missing from _lib.SIGNATURES"
 
 
 def test_oracle_exports_cpu_twins(oracle):
     lib = oracle.lib()
     for name in _declared():
-        if name in ("vus_abi_version", "vus_last_error", "vus_ba_work_doubles", "vus_nav_work_doubles", "vus_ba_band_solve_work_doubles"):
+        if name in HOST_ONLY or name == "vus_ba_set_tuning":
             continue
         assert hasattr(lib, name + "_cpu"), f"oracle lacks {name}_cpu"
 
@@ -61,3 +64,19 @@ def test_product_never_imports_the_oracle():
                 txt = open(os.path.join(dirpath, f)).read()
                 for b in banned:
                     assert b not in txt, f"{f} mentions {b!r}"
+
+
+def test_tuning_knobs_round_trip_without_a_gpu():
+    """vus_ba_set_tuning / vus_ba_get_tuning: host-only, validated, process-wide."""
+    import visual_underwater_slam_amd._lib as L
+    lib = L.load()
+    before = lib.vus_ba_get_tuning(L.TUNE_BAND_MODE), lib.vus_ba_get_tuning(L.TUNE_CB_MAX_WG)
+    try:
+        L.call("vus_ba_set_tuning", L.TUNE_BAND_MODE, 1)
+        L.call("vus_ba_set_tuning", L.TUNE_CB_MAX_WG, 3)
+        assert (lib.vus_ba_get_tuning(L.TUNE_BAND_MODE), lib.vus_ba_get_tuning(L.TUNE_CB_MAX_WG)) == (1, 3)
+        assert lib.vus_ba_set_tuning(L.TUNE_BAND_MODE, 7) == -1 and b"band mode" in lib.vus_last_error()
+        assert lib.vus_ba_set_tuning(99, 0) == -1
+    finally:
+        L.call("vus_ba_set_tuning", L.TUNE_BAND_MODE, before[0])
+        L.call("vus_ba_set_tuning", L.TUNE_CB_MAX_WG, before[1])

@@ -235,12 +235,12 @@ def test_gtsam_shaped_optimize_is_a_drop_in(gpu, oracle):
     assert relerr(np.stack([r2.atPose3(X(i)).flat12() for i in range(50)]), got) < 1e-12
 
 
-def test_band_solve_with_several_row_groups_per_workgroup(gpu, oracle, monkeypatch):
+def test_band_solve_with_several_row_groups_per_workgroup(gpu, oracle, band_tuning):
     """Bands wider than the resident workgroup count give one workgroup several row groups of the cooperative
-    back-substitution.  VUS_CB_MAX_WG=3 forces that path on small systems (solver + 2 helpers serving up to 12
+    back-substitution.  The knob VUS_TUNE_CB_MAX_WG = 3 forces that path on small systems (solver + 2 helpers serving up to 12
     row groups); answers must equal numpy's dense solve, status 0."""
     from visual_underwater_slam_amd import _lib
-    monkeypatch.setenv("VUS_CB_MAX_WG", "3")
+    band_tuning(cb_max_wg=3)
     rng = np.random.default_rng(7)
     for nP, B in [(64, 63), (131, 37), (200, 90), (97, 8), (260, 17)]:
         n = 6 * nP
@@ -298,18 +298,15 @@ def _random_band_system(rng, nP, B):
     return A, Sb
 
 
-@pytest.mark.parametrize("max_wg,two_launch,mode", [(None, None, None), ("3", None, None), (None, "0", None), (None, None, "1")])
-def test_two_sided_band_solve_equals_dense_solve(gpu, oracle, monkeypatch, max_wg, two_launch, mode):
+@pytest.mark.parametrize("max_wg,mode", [(None, None), (3, None), (None, 0), (None, 1), (None, 2)])
+def test_two_sided_band_solve_equals_dense_solve(gpu, oracle, band_tuning, max_wg, mode):
     """vus_ba_band_solve_split / _multi_split: elimination from both ends of the band + dense middle system.  Random
     SPD block bands of many shapes (middle exactly `band` poses or up to 15 more, band not a multiple of the panel,
     systems too short to split -> fallback) against numpy; also with several row groups per workgroup forced."""
     from visual_underwater_slam_amd import _lib
-    if max_wg:
-        monkeypatch.setenv("VUS_CB_MAX_WG", max_wg)
-    if two_launch:       # the two halves normally take the TRSM + SYRK launch pair per panel; "0": the fused launch
-        monkeypatch.setenv("VUS_BAND_TWO_LAUNCH", two_launch)
-    if mode:             # default: the halves on two streams; "1": both halves share every launch of one stream
-        monkeypatch.setenv("VUS_BAND_MODE", mode)
+    # mode: None = automatic; 0 the fused launch per panel; 1 both halves share a TRSM + SYRK launch pair on one stream;
+    # 2 a launch pair per half on two streams
+    band_tuning(band_mode=mode, cb_max_wg=max_wg)
     lib = _lib.load()
     rng = np.random.default_rng(11)
     for nP, B in [(33, 9), (97, 8), (131, 37), (200, 90), (260, 17), (64, 20), (57, 1), (500, 60), (40, 30), (20, 3), (333, 41)]:
@@ -374,11 +371,11 @@ def test_two_sided_solve_inside_the_lm_gives_the_one_sided_result(gpu, oracle):
     assert relerr(points2.cpu().numpy(), points1.cpu().numpy()) < 1e-7
 
 
-def test_one_sided_band_solve_with_the_two_launch_panel_step(gpu, monkeypatch):
+def test_one_sided_band_solve_with_the_two_launch_panel_step(gpu, band_tuning):
     """The TRSM + SYRK launch pair (normally used by the two-sided solve) driving a whole one-sided factorisation,
     including bands narrower than a panel, band 0 and shrinking windows at the end of the matrix."""
     from visual_underwater_slam_amd import _lib
-    monkeypatch.setenv("VUS_BAND_TWO_LAUNCH", "1")
+    band_tuning(band_mode=1)
     rng = np.random.default_rng(3)
     for nP, B in [(5, 0), (30, 0), (9, 2), (23, 7), (17, 16), (40, 11), (97, 8), (64, 63), (131, 37), (200, 90)]:
         A, Sb = _random_band_system(rng, nP, B)

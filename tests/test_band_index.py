@@ -1,0 +1,100 @@
+"""Every address the band-solve kernels form inside Sband, swept on the CPU (a masked-lane address
+of cb_load_inv once pointed 2 KB in front of the band, and only a fault on the GPU box showed it).
+
+visual-underwater-slam_amd/csrc/band_index.h holds that arithmetic as __host__ __device__ functions; the kernels of
+ba.hip call them, and tests/native/band_index_check.cpp replays them here for every (panel, thread) the launches of
+factor_launches() / backsolve_launch() create -- built with AddressSanitizer + UBSan, reading a real buffer of the
+band's size, so an out-of-range offset is a sanitizer report as well as a failed count."""
+import ctypes
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "native", "band_index_check.cpp")
+HDR = os.path.join(ROOT, "visual-underwater-slam_amd", "csrc", "band_index.h")
+
+
+@pytest.fixture(scope="module")
+def checker(tmp_path_factory):
+    out = str(tmp_path_factory.mktemp("bandidx") / "libbandidx_check.so")
+    # -static-libasan: the sanitizer runtime comes with the library (python itself is not instrumented, so LD_PRELOAD
+    # would be needed otherwise)
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=undefined", "-fno-sanitize-recover=undefined",
+           SRC, "-o", out]
+    subprocess.check_call(cmd)
+    lib = ctypes.CDLL(out)
+    lib.bandidx_sweep.restype = ctypes.c_longlong
+    lib.bandidx_sweep.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_longlong), ctypes.c_char_p]
+    return lib
+
+
+def sweep(lib, n, band, n_elim=None):
+    touched = ctypes.c_longlong(0)
+    msg = ctypes.create_string_buffer(256)
+    bad = lib.bandidx_sweep(n, band, n if n_elim is None else n_elim, ctypes.byref(touched), msg)
+    return bad, touched.value, msg.value.decode()
+
+
+# (n, band): band 0, narrower than a panel, one short of / exactly / past a panel, not a multiple of 8, n not a multiple
+# of 8, band = n - 1, and the shapes of the GPU tests
+SHAPES = [(1, 0), (5, 0), (30, 0), (9, 2), (23, 7), (17, 16), (40, 11), (97, 8), (64, 63), (131, 37), (57, 1), (33, 9),
+          (200, 90), (260, 17), (64, 20), (20, 3), (333, 41), (41, 40), (48, 6), (49, 7), (50, 8), (120, 10)]
+
+
+@pytest.mark.parametrize("n,band", SHAPES)
+def test_every_band_address_lies_inside_the_band(checker, n, band):
+    bad, touched, msg = sweep(checker, n, band)
+    assert bad == 0, msg
+    assert touched > 0
+
+
+@pytest.mark.parametrize("n,band", [(131, 37), (200, 90), (333, 41), (97, 8), (500, 60)])
+def test_partial_factorisation_of_the_two_sided_solve(checker, n, band):
+    """The halves of the two-sided solve: systems of m + band poses of which the first m (a multiple of 8) are eliminated
+    and back-substituted."""
+    m = ((n - band) // 2 // 8) * 8
+    assert m >= 8
+    bad, touched, msg = sweep(checker, m + band, band, n_elim=m)
+    assert bad == 0, msg
+
+
+def test_sweep_under_address_sanitizer():
+    """The same sweep in a child process whose checker is built with -fsanitize=address (the python interpreter is not
+    instrumented, so ASan's runtime must be preloaded: a child process with LD_PRELOAD)."""
+    import sys
+    import tempfile
+    asan = subprocess.run(["g++", "-print-file-name=libasan.so"], capture_output=True, text=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found next to g++")
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "libbandidx_asan.so")
+        subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fsanitize=address,undefined",
+                               "-fno-sanitize-recover=all", SRC, "-o", out])
+        code = ("import ctypes, sys\n"
+                f"lib = ctypes.CDLL({out!r})\n"
+                "lib.bandidx_sweep.restype = ctypes.c_longlong\n"
+                "lib.bandidx_sweep.argtypes = [ctypes.c_int] * 3 + [ctypes.c_void_p, ctypes.c_char_p]\n"
+                "msg = ctypes.create_string_buffer(256)\n"
+                "bad = 0\n"
+                "for n, band in [(1, 0), (23, 7), (41, 40), (97, 8), (131, 37), (200, 90), (57, 1)]:\n"
+                "    bad += lib.bandidx_sweep(n, band, n, None, msg)\n"
+                "for n, band in [(131, 37), (97, 8)]:\n"
+                "    m = ((n - band) // 2 // 8) * 8\n"
+                "    bad += lib.bandidx_sweep(m + band, band, m, None, msg)\n"
+                "print('BAD', bad, msg.value.decode())\n"
+                "sys.exit(1 if bad else 0)\n")
+        env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0")
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_the_checker_does_catch_an_address_in_front_of_the_band(checker):
+    """The failure of round 2, replayed: cb_load_inv's column base WITHOUT the masked-lane guard (first panel, lane 47:
+    247 doubles = ~2 KB in front of the band) is counted as a violation by the same touch() the sweeps use."""
+    checker.bandidx_selftest_unguarded.restype = ctypes.c_longlong
+    checker.bandidx_selftest_unguarded.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_char_p]
+    msg = ctypes.create_string_buffer(256)
+    assert checker.bandidx_selftest_unguarded(131, 37, msg) == 1
+    assert b"unguarded cb_load_inv: offset -247" in msg.value

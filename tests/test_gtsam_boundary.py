@@ -244,6 +244,11 @@ def test_values_array_blocks_behave_like_individually_inserted_variables():
     c = Values(b)                                                       # copies are independent
     c.update(L(3), np.array([1.0, 2.0, 3.0]))
     c.update(X(3), Pose3())
+    for key, wrong in ((L(3), Pose3()), (X(3), np.zeros(3)), (L(3), np.zeros(6))):     # type change through update()
+        with pytest.raises(RuntimeError, match="holds a"):
+            c.update(key, wrong)
+        with pytest.raises(RuntimeError, match="holds a"):
+            c.insert_or_assign(key, wrong)
     assert c.atPoint3(L(3)).tolist() == [1.0, 2.0, 3.0] and np.array_equal(b.atPoint3(L(3)), a.atPoint3(L(3)))
     assert c.atPose3(X(3)).equals(Pose3(), 0.0) and not b.atPose3(X(3)).equals(Pose3(), 1e-9)
     c.erase(L(3))

@@ -7,5 +7,5 @@ cd /tmp && export TMPDIR=/tmp
 run() { tag=$1; shift; rm -rf /tmp/prof_$tag; env "$@" rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$tag -- python3 $ROOT/tools/ba_profile.py > /dev/null 2>&1; echo "== $tag ($*)"; python3 $ROOT/tools/summarize_stats.py /tmp/prof_$tag 12 | grep -v "at::native\|rocprim\|rocclr" | tee $OUT/stats_$tag.txt; }
 run default A=1
 
-run fused VUS_BAND_TWO_LAUNCH=0
+run fused VUS_BAND_MODE=0
 

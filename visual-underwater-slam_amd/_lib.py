@@ -43,7 +43,11 @@ SIGNATURES = {
     "vus_nav_border_solve": [c_int, _P, _P, _P, _P, c_double, _P, _P, _P],
     "vus_nav_eval_step": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "vus_nav_error": [_P, c_int, _P, _P, _P, _P, _P, _P],
+    # host-only tuning knobs of the band solve (tests, A/B timing)
+    "vus_ba_set_tuning": [c_int, c_int],
 }
+
+TUNE_BAND_MODE, TUNE_CB_MAX_WG = 0, 1       # VUS_TUNE_* of include/vus.h
 
 
 class VusError(RuntimeError):
@@ -76,6 +80,8 @@ def load():
     lib.vus_ba_work_doubles.restype = ctypes.c_longlong
     lib.vus_ba_band_solve_work_doubles.argtypes = [c_int, c_int, c_int]
     lib.vus_ba_band_solve_work_doubles.restype = ctypes.c_longlong
+    lib.vus_ba_get_tuning.argtypes = [c_int]
+    lib.vus_ba_get_tuning.restype = c_int
     lib.vus_nav_work_doubles.argtypes = [_P]
     lib.vus_nav_work_doubles.restype = ctypes.c_longlong
     _lib = lib

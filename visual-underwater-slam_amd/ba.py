@@ -180,8 +180,11 @@ class StereoBASolver:
         self.new_poses = torch.empty((nP, 12), **f64)
         self.new_points = torch.empty((nL, 3), **f64)
         self.work = torch.empty((2 * (nL + 1) + 8,), **f64)
-        self.scal = torch.zeros((4,), **f64)          # [0] linearise error, [1] lin. error at step, [2] new error
-        self.status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        # one 40-byte record per lambda trial, read back with ONE device-to-host copy: [0] linearise error, [1] linearised
+        # error at the step, [2] new error, [3] spare, [4] (as two int32) the band solve's status word
+        self._trial = torch.zeros((5,), **f64)
+        self.scal = self._trial[:4]
+        self.status = self._trial[4:].view(torch.int32)[:1]
         # two-sided band solve (vus_ba_band_solve_split): worth it once the chain of panel steps is much longer than
         # the band; its workspace (pose-reversed copy of the lower half + the middle system) is allocated once
         self.band_rhs = 1
@@ -267,8 +270,8 @@ class StereoBASolver:
                 self.band_solve()
                 self.backsub()
                 self.eval_step(poses, points)
-                sc = self.scal.cpu()                              # one sync per trial
-                status = int(self.status.item())
+                rec = self._trial.cpu()                           # the trial's ONE blocking read
+                sc, status = rec[:4], int(rec[4:].view(torch.int32)[0])
                 if status < 0:
                     raise RuntimeError("vus_ba_band_solve: the cooperative back-substitution timed out (status %d)" % status)
                 rep.tries += 1
@@ -452,8 +455,8 @@ class NavBASolver(StereoBASolver):
                 self.backsub()
                 self.eval_step(poses, points)
                 self.nav_eval_step(poses, vels, bias)
-                sc, nsc = self.scal.cpu(), self.nav_scal.cpu()
-                status = int(self.status.item())
+                rec = self._trial.cpu()                           # stereo scalars + status, then the inertial scalars
+                sc, status, nsc = rec[:4], int(rec[4:].view(torch.int32)[0]), self.nav_scal.cpu()
                 if status < 0:
                     raise RuntimeError("vus_ba_band_solve: the cooperative back-substitution timed out (status %d)" % status)
                 rep.tries += 1

@@ -28,11 +28,37 @@
 //                flag-ordered sweep) / split_* (two-sided elimination: both ends of the band at once)
 //   backsub      wave / point      dl = -Vinv (gl + sum W^T dp)
 //   retract, eval_points, error_points, reduce_partials
+#include <atomic>
 #include <cstdlib>
+#include <memory>
 #include <mutex>
+#include <vector>
 #include "vus_common.h"
+#include "band_index.h"
 
 namespace {
+
+// Tuning knobs (include/vus.h, vus_ba_set_tuning): the environment is read ONCE, when the library is loaded.
+struct Knobs {
+  std::atomic<int> band_mode{-1};
+  std::atomic<int> cb_max_wg{0};
+  Knobs() {
+    if (const char* e = getenv("VUS_BAND_MODE")) band_mode = atoi(e);
+    if (const char* e = getenv("VUS_CB_MAX_WG")) cb_max_wg = atoi(e);
+  }
+};
+Knobs g_knobs;
+
+// compute units of the current device (cached per device)
+int device_cu_count() {
+  static std::mutex mu;
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cached[dev] && hipDeviceGetAttribute(&cached[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cached[dev] = 0;
+  return cached[dev];
+}
 
 constexpr double kEps = 2.220446049250313e-16;
 constexpr double kPi = 3.14159265358979323846;
@@ -640,14 +666,11 @@ __global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const d
 // block-band Cholesky, right-looking, panels of PB poses (NB = 6 PB scalar columns).
 // Sband entry (i, s) is the 6x6 block (i, i - s), s in [0, band].
 //
-// Per panel three launches:
-//   chol_panel   4 waves; lane R keeps row R of the 48x48 diagonal block in registers, split by
-//                columns over the waves (the right-hand side rides along as row 48), 48 fully
-//                unrolled column steps, the pivot column is broadcast through a double-buffered
-//                LDS vector (one barrier per step); no divides in the loop (v_rsq_f64 + Newton);
-//   chol_trsm    one scalar row of the window per lane, x[48] in registers, L_D broadcast from LDS;
-//   chol_update  SYRK of the window, 96x96 tiles, v_mfma_f64_16x16x4_f64 (K = 48): the only
-//                GEMM-shaped part of the path and where the factorisation's flops are.
+// A panel step = the panel's 48x48 diagonal block factored (panel_factor: four waves, lane = row, 6-column block
+// steps, the right-hand sides ride along as extra rows), the window's rows solved against it (block forward
+// substitution on the matrix cores, stage_and_solve) and the window updated (SYRK tiles of 48x48 on
+// v_mfma_f64_16x16x4_f64).  How the steps are issued -- one fused launch per panel, a TRSM + SYRK launch pair, or the
+// persistent window kernel -- is decided in factor_launches().
 constexpr int PB = 8;
 constexpr int NB = 6 * PB;
 constexpr int LDD = NB + 1;
@@ -709,7 +732,7 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
   const int R = lane;                 // rows 0..nb-1: block rows; rows nb..nb+n_rhs-1: the right-hand sides
-  const int ii = R / 6, rr = R - 6 * ii;
+  const int ii = R / 6;
   const bool is_rhs = R >= nb && R < nb + n_rhs;
   double* yrow = yv + (size_t)(is_rhs ? R - nb : 0) * ystride + 6 * (size_t)k0;
   if (threadIdx.x == 0) s_bad = 0x7FFFFFFF;
@@ -719,9 +742,9 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
     const int kb = wave + 4 * j;
 #pragma unroll
     for (int c = 0; c < 6; ++c) row[j][c] = 0.0;
-    if (R < nb && kb <= ii && ii - kb <= band) {
-      const double* src = (FROM_LDS && ii < lds_poses) ? lds_tile + R * LDD + 6 * kb
-                                                       : blk_ptr(Sb, band, k0 + ii, k0 + kb) + 6 * rr;
+    const long long o_row = bandidx::panel_row(band, k0, nb, R, kb);
+    if (o_row >= 0) {
+      const double* src = (FROM_LDS && ii < lds_poses) ? lds_tile + R * LDD + 6 * kb : Sb + o_row;
 #pragma unroll
       for (int c = 0; c < 6; ++c) row[j][c] = src[c];
     }
@@ -803,8 +826,9 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int kb = wave + 4 * j;
-    if (R < nb && kb <= ii && ii - kb <= band) {
-      double* dst = blk_ptr(Sb, band, k0 + ii, k0 + kb) + 6 * rr;
+    const long long o_row = bandidx::panel_row(band, k0, nb, R, kb);
+    if (o_row >= 0) {
+      double* dst = Sb + o_row;
 #pragma unroll
       for (int c = 0; c < 6; ++c) dst[c] = (6 * kb + c <= R) ? row[j][c] : 0.0;   // strict upper part of the diagonal blocks = 0
     }
@@ -885,15 +909,9 @@ __device__ __forceinline__ void stage_and_solve(const double* __restrict__ Sb, i
 #pragma unroll
     for (int u = 0; u < XU; ++u) {
       const int item = tid + 256 * u;
-      const int tile = (item >= ITEMS) + (item >= 2 * ITEMS);
-      const int e = item - ITEMS * tile;
-      const int lr = e >> 3, kk = e & 7;
-      const int ii = lr / 6, rr = lr - 6 * ii;
-      const int pose = (tile == 0 ? k0 : tile == 1 ? pose0_a : pose0_b) + ii;
-      bool have = item < (1 + n_tiles) * ITEMS && kk < pb;
-      if (tile == 0) have = have && ii < pb && kk <= ii && ii - kk <= band;
-      else have = have && pose <= i_last && kk >= pose - band - k0;
-      const double* src = have ? blk_ptr(Sb, band, pose, k0 + kk) + 6 * rr : Sb;
+      const long long o_item = bandidx::stage_item(band, k0, pb, i_last, pose0_a, pose0_b, n_tiles, item);
+      const bool have = o_item >= 0;
+      const double* src = have ? Sb + o_item : Sb;
       const d2a_t* s2 = reinterpret_cast<const d2a_t*>(src);
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
@@ -1070,9 +1088,9 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(BandSet S, int ba
     for (int e = tid; e < UTP * PB * 6; e += 256) {
       const int ii = e / (6 * PB), rem = e - 6 * PB * ii;
       const int kk = rem / 6, c = rem - 6 * kk;
-      const int i = p0 + ii;
-      if (i <= i_last && kk < pbp && kk >= max(0, i - band - k0_prev)) {
-        double* b = blk_ptr(Sb, band, i, k0_prev + kk) + 6 * c;
+      const long long o_blk = bandidx::solved_item(band, k0_prev, pbp, i_last, p0, e);
+      if (o_blk >= 0) {
+        double* b = Sb + o_blk;
 #pragma unroll
         for (int r = 0; r < 6; ++r) b[r] = Xi[(6 * ii + r) * ULD + 6 * kk + c];
       }
@@ -1091,16 +1109,6 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(BandSet S, int ba
   const int pi0 = i_first + ti * UTP, pj0 = i_first + tj * UTP;   // first pose of the tile rows / columns
   const double* Xjj = (ti == tj) ? Xi : Xj;
   const int arow = lane & 15, kq = lane >> 4;
-  // element (row Rr of pose i, column Cc of pose j) lives at rowoff + coloff: the offsets separate
-  long long coloff[UMT];
-  int cj[UMT], ccm[UMT];
-#pragma unroll
-  for (int b = 0; b < UMT; ++b) {
-    const int Cc = 16 * b + arow;
-    cj[b] = pj0 + Cc / 6;
-    ccm[b] = Cc % 6;
-    coloff[b] = -36ll * cj[b] + ccm[b];
-  }
   // this wave's MFMA tiles: accumulate X_i X_j^T - A and store the negation, so the old values enter
   // as the C operand (their loads are in flight during the solve) instead of a read-modify-write tail
   double4_t acc[UQ];
@@ -1112,10 +1120,9 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(BandSet S, int ba
     const int a = t / UMT, b = t - UMT * a;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int Rr = 16 * a + kq + 4 * r;
-      const int i = pi0 + Rr / 6, rm = Rr % 6;
-      ok[q][r] = t < UMT * UMT && i <= i_last && cj[b] <= i && (cj[b] < i || ccm[b] <= rm);
-      off[q][r] = ok[q][r] ? 36ll * ((long long)i * (band + 2)) + 6 * rm + coloff[b] : 0;
+      const long long o_el = t < UMT * UMT ? bandidx::tile_scalar(band, i_last, pi0, pj0, 16 * a + kq + 4 * r, 16 * b + arow) : -1;
+      ok[q][r] = o_el >= 0;
+      off[q][r] = ok[q][r] ? o_el : 0;
       acc[q][r] = -Sb[off[q][r]];
     }
   }
@@ -1219,9 +1226,9 @@ __global__ __launch_bounds__(256) void chol_trsm_kernel(BandSet S, int band, int
   for (int e = tid; e < UTP * PB * 6; e += 256) {
     const int ii = e / (6 * PB), rem = e - 6 * PB * ii;
     const int kk = rem / 6, c = rem - 6 * kk;
-    const int i = p0 + ii;
-    if (i <= i_last && kk < pb && kk >= max(0, i - band - k0)) {
-      double* b = blk_ptr(Sb, band, i, k0 + kk) + 6 * c;
+    const long long o_blk = bandidx::solved_item(band, k0, pb, i_last, p0, e);
+    if (o_blk >= 0) {
+      double* b = Sb + o_blk;
 #pragma unroll
       for (int r = 0; r < 6; ++r) b[r] = Xi[(6 * ii + r) * ULD + 6 * kk + c];
     }
@@ -1249,9 +1256,9 @@ __device__ __forceinline__ void stage_solved_tile(const double* __restrict__ Sb,
   for (int item = first; item < UTP * PB * 6; item += step) {      // (pose ii, panel pose kk, column c): 6 rows
     const int ii = item / (6 * PB), rem = item - 6 * PB * ii;
     const int kk = rem / 6, c = rem - 6 * kk;
-    const int pose = pose0 + ii;
-    const bool have = pose <= i_last && kk < pb && kk >= pose - band - k0;
-    const d2a_t* src = reinterpret_cast<const d2a_t*>(have ? blk_ptr(Sb, band, pose, k0 + kk) + 6 * c : Sb);
+    const long long o_blk = bandidx::solved_item(band, k0, pb, i_last, pose0, item);
+    const bool have = o_blk >= 0;
+    const d2a_t* src = reinterpret_cast<const d2a_t*>(have ? Sb + o_blk : Sb);
     d2a_t v0 = src[0], v1 = src[have ? 1 : 0], v2 = src[have ? 2 : 0];
     if (!have) v0 = v1 = v2 = d2a_t{0.0, 0.0};
     double* dst = X + (6 * ii) * ULD + 6 * kk + c;
@@ -1290,16 +1297,11 @@ __global__ __launch_bounds__(256, 4) void chol_syrk_kernel(BandSet S, int band, 
   unsigned vmask[CV];                                  // bit 0/1: element 0/1 of the vector is part of the band's lower part
 #pragma unroll
   for (int u = 0; u < CV; ++u) {
-    const int v = tid + 256 * u;
-    const int ii = v / 144, w = v - 144 * ii;
-    const int o = w / 18, e = 2 * (w - 18 * o);
-    const int i = pi0 + ii, j = pj0 + 7 - o;
-    const int rr = e / 6, c = e - 6 * rr;
-    unsigned m = 0;
-    if (v < UTP * 144 && i <= i_last && j <= i) m = (j < i) ? 3u : ((c <= rr ? 1u : 0u) | (c + 1 <= rr ? 2u : 0u));
+    unsigned m;
+    const long long o_vec = bandidx::tile_vec(band, i_last, pi0, pj0, tid + 256 * u, m);
     vmask[u] = m;
     oldv[u] = d2a_t{0.0, 0.0};
-    if (m) oldv[u] = *reinterpret_cast<const d2a_t*>(Sb + 36 * ((long long)i * (band + 1) + (i - j)) + e);
+    if (m) oldv[u] = *reinterpret_cast<const d2a_t*>(Sb + o_vec);
   }
   if (ti == tj) {
     stage_solved_tile(Sb, band, k0, pb, i_last, pi0, Xi, tid, tid, 256);
@@ -1353,11 +1355,9 @@ __global__ __launch_bounds__(256, 4) void chol_syrk_kernel(BandSet S, int band, 
 #pragma unroll
   for (int u = 0; u < CV; ++u) {
     if (!vmask[u]) continue;
-    const int v = tid + 256 * u;
-    const int ii = v / 144, w = v - 144 * ii;
-    const int o = w / 18, e = 2 * (w - 18 * o);
-    const int i = pi0 + ii, j = pj0 + 7 - o;
-    *reinterpret_cast<d2a_t*>(Sb + 36 * ((long long)i * (band + 1) + (i - j)) + e) = oldv[u];
+    unsigned m;
+    const long long o_vec = bandidx::tile_vec(band, i_last, pi0, pj0, tid + 256 * u, m);
+    *reinterpret_cast<d2a_t*>(Sb + o_vec) = oldv[u];
   }
   if (crit) {
     // Tile (0,0) is the next panel's diagonal block, complete once this workgroup has stored it: factor it here.
@@ -1430,14 +1430,7 @@ __device__ __forceinline__ bool cb_wait(const int* f, int need, int* abort_flag)
 // Slot t of the lower block triangle of a panel: block row r6, distance sd from the diagonal block, element e.
 constexpr int CB_DIAG_ELEMS = 36 * (PB * (PB + 1) / 2);
 constexpr int CB_DIAG_PER_LANE = (CB_DIAG_ELEMS + 63) / 64;
-__device__ __forceinline__ void cb_diag_slot(int t, int& r6, int& sd, int& e) {
-  r6 = 0;
-#pragma unroll
-  for (int q = 1; q < PB; ++q) r6 += t >= 36 * (q * (q + 1) / 2);
-  const int u = t - 36 * (r6 * (r6 + 1) / 2);
-  sd = u / 36;          // block (k0 + r6, k0 + r6 - sd)
-  e = u - 36 * sd;
-}
+static_assert(CB_DIAG_ELEMS == bandidx::DIAG_ELEMS && PB == bandidx::PB && NB == bandidx::NB && UTP == bandidx::UTP, "band_index.h");
 
 __global__ __launch_bounds__(64) void diag_invert_kernel(BandSet S, int band, int n_solve) {
   const int sysi = blockIdx.y, p = blockIdx.x, lane = threadIdx.x;
@@ -1459,11 +1452,9 @@ __global__ __launch_bounds__(64) void diag_invert_kernel(BandSet S, int band, in
 #pragma unroll
   for (int j = 0; j < CB_DIAG_PER_LANE; ++j) {
     const int t = lane + 64 * j;
-    int r6, sd, e;
-    cb_diag_slot(t < CB_DIAG_ELEMS ? t : 0, r6, sd, e);
-    const bool h = t < CB_DIAG_ELEMS && 6 * r6 < nb && sd <= band;
-    have |= (unsigned)h << j;
-    src[j] = h ? Sb + 36 * ((size_t)(k0 + r6) * (band + 1) + sd) + e : Sb;
+    const long long o_el = bandidx::diag_elem(band, k0, nb, t);
+    have |= (unsigned)(o_el >= 0) << j;
+    src[j] = o_el >= 0 ? Sb + o_el : Sb;
   }
 #pragma unroll
   for (int j = 0; j < CB_DIAG_PER_LANE; ++j) v[j] = *src[j];
@@ -1471,7 +1462,7 @@ __global__ __launch_bounds__(64) void diag_invert_kernel(BandSet S, int band, in
   for (int j = 0; j < CB_DIAG_PER_LANE; ++j) {
     const int t = lane + 64 * j;
     int r6, sd, e;
-    cb_diag_slot(t < CB_DIAG_ELEMS ? t : 0, r6, sd, e);
+    bandidx::diag_slot(t < CB_DIAG_ELEMS ? t : 0, r6, sd, e);
     if ((have >> j) & 1) sL[(6 * r6 + e / 6) * (NB + 1) + 6 * (r6 - sd) + e % 6] = v[j];
   }
   __syncthreads();
@@ -1495,24 +1486,24 @@ __global__ __launch_bounds__(64) void diag_invert_kernel(BandSet S, int band, in
   for (int j = 0; j < CB_DIAG_PER_LANE; ++j) {
     const int t = lane + 64 * j;
     int r6, sd, e;
-    cb_diag_slot(t < CB_DIAG_ELEMS ? t : 0, r6, sd, e);
+    bandidx::diag_slot(t < CB_DIAG_ELEMS ? t : 0, r6, sd, e);
     if ((have >> j) & 1)
-      Sb[36 * ((size_t)(k0 + r6) * (band + 1) + sd) + e] = sI[(6 * r6 + e / 6) * (NB + 1) + 6 * (r6 - sd) + e % 6];
+      Sb[bandidx::diag_elem(band, k0, nb, t)] = sI[(6 * r6 + e / 6) * (NB + 1) + 6 * (r6 - sd) + e % 6];
   }
 }
 
 // column `lane` of the diagonal block, pre-scaled: Lp[c] = L[c][lane] / L[lane][lane] for c > lane, else 0
 __device__ __forceinline__ void cb_load_diag(const double* __restrict__ Sb, int band, int k0, int nb, int lane,
                                              double (&Lp)[NB], double& dinv) {
-  const int lr6 = lane / 6, lrm = lane - 6 * lr6;
 #pragma unroll
   for (int c = 0; c < NB; ++c) {
-    const bool have = c < nb && lane < c && c / 6 - lr6 <= band;
-    const double* src = have ? blk_ptr(Sb, band, k0 + c / 6, k0 + lr6) + 6 * (c % 6) + lrm : Sb;
+    const long long o_el = bandidx::cb_diag(band, k0, nb, lane, c);
+    const double* src = o_el >= 0 ? Sb + o_el : Sb;
     Lp[c] = *src;
-    if (!have) Lp[c] = 0.0;
+    if (o_el < 0) Lp[c] = 0.0;
   }
-  const double dg = lane < nb ? blk_ptr(Sb, band, k0 + lr6, k0 + lr6)[7 * lrm] : 1.0;
+  const long long o_piv = bandidx::cb_diag_pivot(band, k0, nb, lane);
+  const double dg = o_piv >= 0 ? Sb[o_piv] : 1.0;
   dinv = 1.0 / dg;
 #pragma unroll
   for (int c = 0; c < NB; ++c) Lp[c] *= dinv;
@@ -1523,16 +1514,15 @@ __device__ __forceinline__ void cb_load_diag(const double* __restrict__ Sb, int 
 // of every address is the same for all lanes.
 __device__ __forceinline__ void cb_load_inv(const double* __restrict__ Sb, int band, int k0, int nb, int lane,
                                             double (&Lp)[NB]) {
-  const int ln = lane < NB ? lane : 0;
-  const int c6 = ln / 6, cm = ln - 6 * c6;
-  const double* col = Sb + 36 * (size_t)k0 * (band + 1) + (cm - 36 * c6);    // element (row 0 of the panel, column ln)
-  const int stride = 36 * (band + 2);                                         // one block row down, same block column
   // entries above the diagonal (and rows >= nb of a short last panel) are not stored: those lanes read the panel's
-  // first element instead.  All 48 loads are issued before the first result is looked at.
-  const double* safe = Sb + 36 * (size_t)k0 * (band + 1);
+  // first element instead (bandidx::cb_inv_safe; an earlier version formed an address 2 KB in front of the band for
+  // them).  One per-lane base, the rest of every address is the same for all lanes; all 48 loads are issued before
+  // the first result is looked at.
+  const double* safe = Sb + bandidx::cb_inv_safe(band, k0);
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
-    const double* src = (r < nb && lane <= r) ? col + ((r / 6) * stride + 6 * (r % 6)) : safe;
+    const long long o_el = bandidx::cb_inv(band, k0, nb, lane, r);
+    const double* src = o_el >= 0 ? Sb + o_el : safe;
     Lp[r] = *src;
   }
 #pragma unroll
@@ -1573,9 +1563,9 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
   bool have;
 #define CB_LOAD_ROWS_G(P, G)                                                                           \
   {                                                                                                    \
-    const int k0_ = PB * (P), i_ = k0_ - PB * (G) - PB + a;                                            \
-    have = kk < PB && i_ >= 0 && k0_ + kk < n_poses && k0_ + kk - i_ <= band;                                     \
-    const d2a_t* src_ = reinterpret_cast<const d2a_t*>(have ? blk_ptr(Sb, band, k0_ + kk, i_) + 6 * c : Sb); \
+    const long long o_ = bandidx::cb_rows(band, n_poses, (P), (G), kk, a, c);                          \
+    have = o_ >= 0;                                                                                    \
+    const d2a_t* src_ = reinterpret_cast<const d2a_t*>(have ? Sb + o_ : Sb);                           \
     l[0] = src_[0]; l[1] = src_[1]; l[2] = src_[2];                                                    \
   }
 #define CB_PARTIAL_DOTS()                                                                              \
@@ -1907,19 +1897,13 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
   if (nO > 0 && Y != nullptr) ymul_kernel<<<cdiv(nO, 256), 256, 0, st>>>(*P, W, Vinv, Y);   // optional output only
   schur_init_kernel<<<cdiv(36ll * nP, 256), 256, 0, st>>>(nP, S->band, ps, lambda, Hpp, Sband);
   if (S->n_blocks > 0) {
-    static bool lds_set = false;
     constexpr int lds = SR_ROWS * SR_LD * (int)sizeof(double);
-    if (!lds_set) {
-      VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(schur_rows_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-      lds_set = true;
-    }
+    // (kernel, device) attribute: set per call -- a host-side table write -- instead of once per process
+    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(schur_rows_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     // one workgroup per CU (it owns 144 KB of LDS), persistent over the rows of its XCD's range
-    static int n_cu = 0;
-    if (!n_cu) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
-    }
+    int n_cu = device_cu_count();
+    if (n_cu < 8) n_cu = 256;
     int wg = 8 * (n_cu / 8);
     if (wg > 8 * ((nP + 7) / 8)) wg = 8 * ((nP + 7) / 8);
     schur_rows_kernel<<<wg, SR_THREADS, lds, st>>>(*S, P->pose_ptr, P->pobs_lidx, P->obs_point, nP, ps, W, Vinv, Sband);
@@ -1955,9 +1939,8 @@ int* flags_fallback() {
 // this kernel times the compute units of the device, less a margin of one workgroup per eight CUs (the query can
 // read one block per CU high, MI355X_MICROARCH.md "Residency and cooperative launch").  The waits are bounded, so a
 // workgroup that is not resident after all (another stream holding CUs) ends in status -1, not in a hang.
-// VUS_CB_MAX_WG (compile time) and the
-// environment variable of the same name (run time, used by the tests to force several row groups per
-// workgroup) cap it further.
+// VUS_CB_MAX_WG (compile time) and the tuning knob VUS_TUNE_CB_MAX_WG (run time, used by the tests to force several
+// row groups per workgroup) cap it further.
 int backsolve_max_wg() {
   static std::mutex mu;
   static int cached[64] = {};
@@ -1976,10 +1959,8 @@ int backsolve_max_wg() {
     cap = cached[dev];
   }
   if (cap > CB_MAX_WG) cap = CB_MAX_WG;
-  if (const char* e = getenv("VUS_CB_MAX_WG")) {
-    const int v = atoi(e);
-    if (v >= 1 && v < cap) cap = v;
-  }
+  const int v = g_knobs.cb_max_wg.load(std::memory_order_relaxed);
+  if (v >= 1 && v < cap) cap = v;
   return cap;
 }
 
@@ -1990,7 +1971,7 @@ int backsolve_max_wg() {
 int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st, hipStream_t st2 = nullptr) {
   const int n = S.s[0].n;
   const bool full = n_elim >= n;
-  // Three ways to issue a panel step (VUS_BAND_MODE = 0 / 1 / 2 forces one; tests and A/B timing):
+  // Three ways to issue a panel step (the knob VUS_TUNE_BAND_MODE = 0 / 1 / 2 forces one; tests and A/B timing):
   //  0  fused launch: every update tile solves its rows itself -- one system;
   //  1  TRSM launch + SYRK launch shared by both systems (rows solved once, light update tiles, one round);
   //  2  the two systems on two STREAMS, a (TRSM, SYRK) launch pair each per panel, issued alternately: the halves of
@@ -1998,8 +1979,10 @@ int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream
   //     (band solve at configs[2]: mode 0 4.64 ms, mode 1 4.31 ms, mode 2 4.11 ms; the fused launch per half on two
   //     streams was measured too: 4.15 ms).
   int mode = S.count == 2 ? (st2 ? 2 : 1) : 0;
-  if (const char* e = getenv("VUS_BAND_TWO_LAUNCH")) mode = atoi(e) != 0 ? (S.count == 2 && st2 && mode == 2 ? 2 : 1) : 0;
-  if (const char* e = getenv("VUS_BAND_MODE")) { const int m = atoi(e); if (m == 0 || m == 1 || (m == 2 && S.count == 2 && st2)) mode = m; }
+  {
+    const int m = g_knobs.band_mode.load(std::memory_order_relaxed);
+    if (m == 0 || m == 1 || (m == 2 && S.count == 2 && st2)) mode = m;
+  }
   BandSet one[2];
   hipStream_t sts[2] = {st, st2};
   int n_sets = 1;
@@ -2048,27 +2031,66 @@ int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream
   return VUS_OK;
 }
 
-// A second stream and two events per device for the two-sided solve's fork / join (created once, never destroyed).
+// The two-sided solve forks onto an auxiliary stream.  That stream and its fork / join events belong to ONE caller
+// stream of ONE device (created on first use, never destroyed): two host threads that solve on their own streams share
+// nothing, so neither can re-record an event the other is about to wait on.  The entry's mutex is held from the first
+// fork to the last join of a call: two threads that do share a caller stream serialise their (host-side) enqueue
+// sections instead of interleaving them.
 struct SplitAux {
+  int dev = -1;
+  hipStream_t key = nullptr;
   hipStream_t s2 = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
-  bool ok = false;
+  std::mutex mu;
 };
-SplitAux* split_aux() {
+SplitAux* split_aux(hipStream_t st) {
   static std::mutex mu;
-  static SplitAux aux[64];
+  static std::vector<std::unique_ptr<SplitAux>> pool;
   int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (hipGetDevice(&dev) != hipSuccess) return nullptr;
   std::lock_guard<std::mutex> lock(mu);
-  SplitAux& a = aux[dev];
-  if (!a.ok) {
-    if (hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    a.ok = true;
+  for (auto& a : pool)
+    if (a->dev == dev && a->key == st) return a.get();
+  std::unique_ptr<SplitAux> a(new SplitAux);
+  a->dev = dev;
+  a->key = st;
+  if (hipStreamCreateWithFlags(&a->s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
+  if (hipEventCreateWithFlags(&a->fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&a->join, hipEventDisableTiming) != hipSuccess) {
+    (void)hipStreamDestroy(a->s2);
+    return nullptr;
   }
-  return &a;
+  pool.push_back(std::move(a));
+  return pool.back().get();
 }
+
+// One fork .. join section on a SplitAux.  Once fork() has succeeded, the caller's stream is made to wait for the
+// auxiliary stream before the section ends -- by join(), or by the destructor on every early return -- so that no
+// buffer of the caller is still in use on the auxiliary stream when the call returns.
+struct SplitSection {
+  SplitAux* a;
+  hipStream_t st;
+  std::unique_lock<std::mutex> lock;
+  bool open = false;
+  SplitSection(SplitAux* aux, hipStream_t s) : a(aux), st(s) {
+    if (a) lock = std::unique_lock<std::mutex>(a->mu);
+  }
+  int fork() {      // s2 continues from this point of st
+    VUS_CHECK_HIP(hipEventRecord(a->fork, st));
+    VUS_CHECK_HIP(hipStreamWaitEvent(a->s2, a->fork, 0));
+    open = true;
+    return VUS_OK;
+  }
+  int join() {      // st continues only after everything issued on s2 so far
+    open = false;
+    VUS_CHECK_HIP(hipEventRecord(a->join, a->s2));
+    VUS_CHECK_HIP(hipStreamWaitEvent(st, a->join, 0));
+    return VUS_OK;
+  }
+  ~SplitSection() {
+    if (open) (void)join();
+  }
+};
 
 // Cooperative back-substitution x = L^-T y of every system of S (n_solve > 0: of its leading n_solve poses only).
 // The diagonal panels of every system of S inverted in place (see diag_invert_kernel); false = band too narrow
@@ -2287,43 +2309,54 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
   S.count = 2;
   S.s[0] = BandSys{Sband, yT, status, nullptr, p.nT};
   S.s[1] = BandSys{Rb, yR, st_R, nullptr, p.nT};
-  SplitAux* aux2 = nullptr;
-  {
-    // the halves are independent chains until the middle system: the pose-reversed one runs on a second stream
-    SplitAux* aux = nullptr;
-    const char* e = getenv("VUS_BAND_MODE");
-    if (!e || atoi(e) == 2) aux = split_aux();
-    if (aux) {
-      VUS_CHECK_HIP(hipEventRecord(aux->fork, st));
-      VUS_CHECK_HIP(hipStreamWaitEvent(aux->s2, aux->fork, 0));
-    }
-    if (int rc = factor_launches(S, band, p.m, n_rhs, st, aux ? aux->s2 : nullptr)) return rc;
-    if (aux) {
-      VUS_CHECK_HIP(hipEventRecord(aux->join, aux->s2));
-      VUS_CHECK_HIP(hipStreamWaitEvent(st, aux->join, 0));
-    }
-    aux2 = aux;
-  }
+  // the halves are independent chains until the middle system: the pose-reversed one runs on a second stream
+  const int mode_knob = g_knobs.band_mode.load(std::memory_order_relaxed);
+  SplitSection sec((mode_knob < 0 || mode_knob == 2) ? split_aux(st) : nullptr, st);
+  if (sec.a)
+    if (int rc = sec.fork()) return rc;
+  if (int rc = factor_launches(S, band, p.m, n_rhs, st, sec.a ? sec.a->s2 : nullptr)) return rc;
+  if (sec.a)
+    if (int rc = sec.join()) return rc;
   // the diagonal panels of both halves are inverted (for their back-substitution) beside the middle system's solve
   bool halves_inverted = false;
-  if (aux2) {
-    VUS_CHECK_HIP(hipEventRecord(aux2->fork, st));
-    VUS_CHECK_HIP(hipStreamWaitEvent(aux2->s2, aux2->fork, 0));
-    halves_inverted = diag_invert_launch(S, band, p.m, aux2->s2);
-    VUS_CHECK_HIP(hipEventRecord(aux2->join, aux2->s2));
+  if (sec.a) {
+    if (int rc = sec.fork()) return rc;
+    halves_inverted = diag_invert_launch(S, band, p.m, sec.a->s2);
   }
   const size_t nM = 36 * (size_t)p.n_mid * (p.bm + 1);
   split_mid_kernel<<<cdiv((long long)nM, 256), 256, 0, st>>>(Sband, y, p, Rb, yT, yR, Mid, yM);
   if (int rc = band_solve_impl(Mid, p.n_mid, p.bm, yM, n_rhs, st_M, st)) return rc;
   const int n_spike = band < p.m ? band : p.m;
   split_spike_kernel<<<dim3(n_spike, 2, n_rhs), 64, 0, st>>>(Sband, Rb, p, yM, yT, yR);
-  if (aux2) VUS_CHECK_HIP(hipStreamWaitEvent(st, aux2->join, 0));
+  if (sec.open)
+    if (int rc = sec.join()) return rc;
   if (int rc = backsolve_launch(S, band, n_rhs, p.m, st, halves_inverted)) return rc;     // the eliminated poses of both halves
   split_gather_kernel<<<cdiv(6ll * n * n_rhs, 256), 256, 0, st>>>(p, yT, yR, yM, y, st_R, st_M, status);
   VUS_CHECK_LAUNCH("ba_band_solve_split");
   return VUS_OK;
 }
 }  // namespace
+
+extern "C" int vus_ba_set_tuning(int knob, int value) {
+  switch (knob) {
+    case VUS_TUNE_BAND_MODE:
+      VUS_REQUIRE(value >= -1 && value <= 2, "band mode %d out of range [-1, 2]", value);
+      g_knobs.band_mode = value;
+      return VUS_OK;
+    case VUS_TUNE_CB_MAX_WG:
+      VUS_REQUIRE(value >= 0, "workgroup cap %d is negative", value);
+      g_knobs.cb_max_wg = value;
+      return VUS_OK;
+    default:
+      return vus::fail(VUS_E_INVALID, "unknown tuning knob %d", knob);
+  }
+}
+
+extern "C" int vus_ba_get_tuning(int knob) {
+  if (knob == VUS_TUNE_BAND_MODE) return g_knobs.band_mode.load();
+  if (knob == VUS_TUNE_CB_MAX_WG) return g_knobs.cb_max_wg.load();
+  return vus::fail(VUS_E_INVALID, "unknown tuning knob %d", knob);
+}
 
 extern "C" int vus_ba_band_solve(double* Sband, int n_poses, int band, const double* gs, double* dp, int* status,
                                  void* stream) {

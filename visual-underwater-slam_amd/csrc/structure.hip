@@ -179,12 +179,10 @@ int check(const vus_ba_problem* P, int band, int& nd, int& words) {
 
 template <bool FILL>
 int prepare(int lds_bytes) {
-  static int lds_max = 0;
-  if (lds_bytes > lds_max) {
-    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(structure_rows_kernel<FILL>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    lds_max = lds_bytes;
-  }
+  // The attribute belongs to (kernel, device): it is set on every call (a host-side table write, no device work)
+  // rather than cached in a process-wide static that a second device or a second thread would read wrongly.
+  VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(structure_rows_kernel<FILL>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
   return VUS_OK;
 }
 

@@ -9,9 +9,11 @@ the two places where the path shards:
              data path, one all_gather of the fixed-size per-frame match records at the end;
   BA         landmarks are independent given the poses -> contiguous landmark ranges ("landmark
              block-rows") per rank, poses replicated.  Each rank linearises and eliminates its own
-             landmarks; the exchange step is ONE all-reduce per lambda trial of the reduced camera
-             system (block band + right-hand side), then the band solve is replicated and the
-             back-substitution is local.  Error scalars are all-reduced for the accept test.
+             landmarks; the exchange step is ONE reduce per lambda trial of the reduced camera system
+             (block band + right-hand side) to rank 0, which solves it and broadcasts the step dp and
+             the solve's status word (half the bytes per link of an all-reduce, and
+             every rank acts on bit-identical values); the back-substitution is local.  Error scalars
+             are all-reduced for the accept test.
 """
 from typing import List, Tuple
 

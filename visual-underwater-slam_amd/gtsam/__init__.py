@@ -418,7 +418,7 @@ class BetweenFactorConstantBias(_Factor):
 
 
 class PreintegrationParams:
-    """Holds the IMU noise parameters batch.py sets at :181-187 (consumed by f1, not built yet)."""
+    """Holds the IMU noise parameters batch.py sets at :181-187 (consumed by gtsam/imu.py's Preintegrator when a PreintegratedImuMeasurements is built from them)."""
 
     def __init__(self, n_gravity):
         self.n_gravity = np.asarray(n_gravity, dtype=float)
@@ -690,7 +690,13 @@ class Values:
         b, i = self._find_block(key)
         if b is not None:
             v = self._coerce(value)
-            b.data[i] = v.flat12() if isinstance(v, Pose3) else np.asarray(v, float).reshape(-1)
+            # gtsam refuses to change a variable's type through update(): same RuntimeError as _at() / _rows()
+            ok = isinstance(v, Pose3) if b.kind == "pose3" else (isinstance(v, np.ndarray) and v.size == 3)
+            if not ok:
+                held = "Pose3" if b.kind == "pose3" else "Point3"
+                raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(key)}\" holds a {held}, "
+                                   f"not the {type(v).__name__} update() was given")
+            b.data[i] = v.flat12() if b.kind == "pose3" else v
             return
         if key not in self._d:
             raise RuntimeError(f"Requested to update a key-value pair with key \"{symbol_shorthand.key_string(key)}\", "
