@@ -146,6 +146,34 @@ int vus_track_ids(const int32_t* stereo_idx, const int32_t* track_idx, const uin
                   const int* kp_count, int n_frames, int max_kp, int H, int W, int64_t* ids_out,
                   double* feat_out, int64_t* n_ids_out, void* stream);
 
+/* batch_update's get_landmarks call per keyframe + batch_create's landmark loop (batch.py:264-265, 295-305) for a whole
+ * sequence of keyframes at once: what the Python loops of the reference turn the CameraMeasurement stream into.
+ *   ids  int64 [n_frames, max_kp]    published feature ids of every keyframe (-1: none), as vus_track_ids emits them
+ *   feat f64   [n_frames, max_kp, 4] their (u0, v0, u1, v1)
+ *   Rt   f64   [n_frames, 12]        zed_world_transform of every keyframe (row-major R then t; batch.py:45-48,166)
+ *   cam  f64   [8]                   as for vus_triangulate
+ * Keyframes < first_frame emit nothing (batch.py:280-305 gives keyframe 0 no landmark loop: first_frame = 1).  For
+ * every feature (f >= first_frame, slot i, id >= 0), in frame-major / slot-ascending order -- the order in which
+ * batch_create pushes its GenericStereoFactor3D factors --
+ *   obs_frame int32 [n], obs_id int64 [n], obs_meas f64 [n,3] = StereoPoint2(uL, uR, v)   (batch.py:300-304)
+ * with n returned in count[0] (n <= n_frames * max_kp: the capacity the caller allocates), and per id < n_ids
+ *   lm_first int64 [n_ids] = f * max_kp + i of its FIRST sighting in those keyframes (-1: never seen there)
+ *   lm_point f64   [n_ids,3] = that sighting's world point, i.e. what batch.py:297-298 inserts as L(id)'s initial value
+ *                              (untouched for ids never seen).
+ * frame_base int32 [n_frames + 1] is scratch (receives the exclusive prefix sum of the per-keyframe feature counts). */
+int vus_emit_stereo_factors(const int64_t* ids, const double* feat, const double* Rt, const double* cam, int n_frames,
+                            int max_kp, int first_frame, long long n_ids, int* frame_base, int* count,
+                            int* obs_frame, int64_t* obs_id, double* obs_meas, int64_t* lm_first, double* lm_point,
+                            void* stream);
+
+/* Unwhitened residual of every emitted stereo factor at the INITIAL estimate -- GenericStereoFactor3D's
+ * h(X(f), L(id)) - measurement with X(f) = Rt[obs_frame], L(id) = lm_point[obs_id], K = (fx, fy, skew, cx, cy, b):
+ *   resid f64 [n,3];  a point at or behind the camera (z <= 0, gtsam's cheirality case) gives +infinity in all three.
+ * EXTENSION (not in the reference, which has no outlier handling of its own: the nodelet's RANSAC precedes it): lets the
+ * caller gate gross mismatches of the brute-force matcher before they enter the graph (sequence.py, gate_px). */
+int vus_stereo_initial_residuals(const double* Rt, const double* K, const double* lm_point, const int* obs_frame,
+                                 const int64_t* obs_id, const double* obs_meas, int n, double* resid, void* stream);
+
 /* get_landmarks of batch.py:144-176, elementwise over n features (fp64):
  *   feat [n,4] = (u0, v0, u1, v1) normalised image coordinates of the CameraMeasurement message,
  *   cam  [8]   = (fx, fy, cx, cy, baseline, resolution_x, resolution_y, unused),

@@ -217,6 +217,35 @@ def triangulate(feat, cam, Rt):
     return out
 
 
+def emit_stereo_factors(ids, feat, Rt, cam, n_ids, first_frame=1):
+    """batch_update + batch_create's landmark loop (batch.py:264-265, 295-305) over all keyframes: returns
+    (obs_frame, obs_id, obs_meas, lm_first, lm_point)."""
+    ids = np.ascontiguousarray(ids, np.int64)
+    F, K = ids.shape
+    feat = np.ascontiguousarray(feat, np.float64); Rt = np.ascontiguousarray(Rt, np.float64).reshape(F, 12)
+    cam = np.ascontiguousarray(cam, np.float64)
+    base = np.zeros(F + 1, np.int32); count = np.zeros(1, np.int32)
+    of = np.zeros(F * K, np.int32); oi = np.zeros(F * K, np.int64); om = np.zeros((F * K, 3), np.float64)
+    first = np.zeros(max(int(n_ids), 1), np.int64); pt = np.zeros((max(int(n_ids), 1), 3), np.float64)
+    _check(lib().vus_emit_stereo_factors_cpu(_p(ids), _p(feat), _p(Rt), _p(cam), F, K, int(first_frame),
+                                             ctypes.c_longlong(int(n_ids)), _p(base), _p(count), _p(of), _p(oi), _p(om),
+                                             _p(first), _p(pt)), "emit_stereo_factors")
+    n = int(count[0])
+    return of[:n], oi[:n], om[:n], first[:int(n_ids)], pt[:int(n_ids)]
+
+
+def stereo_initial_residuals(Rt, K, lm_point, obs_frame, obs_id, obs_meas):
+    Rt = np.ascontiguousarray(Rt, np.float64); K = np.ascontiguousarray(K, np.float64)
+    lm_point = np.ascontiguousarray(lm_point, np.float64)
+    obs_frame = np.ascontiguousarray(obs_frame, np.int32); obs_id = np.ascontiguousarray(obs_id, np.int64)
+    obs_meas = np.ascontiguousarray(obs_meas, np.float64)
+    n = len(obs_frame)
+    out = np.empty((n, 3), np.float64)
+    _check(lib().vus_stereo_initial_residuals_cpu(_p(Rt), _p(K), _p(lm_point), _p(obs_frame), _p(obs_id), _p(obs_meas), n,
+                                                  _p(out)), "stereo_initial_residuals")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # bundle adjustment (oracle/vus_oracle_ba.c)
 class _BAProblem(ctypes.Structure):

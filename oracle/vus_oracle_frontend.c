@@ -471,3 +471,60 @@ int vus_triangulate_cpu(const double* feat, int n, const double* cam, const doub
   }
   return VUS_OK;
 }
+
+/* batch_update's get_landmarks per keyframe (batch.py:264-265) + the landmark loop of batch_create (batch.py:295-305),
+ * as two plain nested loops in the reference's order: keyframes ascending (none before first_frame: batch.py:280-305
+ * has no landmark loop for i == 0), features in message order. */
+int vus_emit_stereo_factors_cpu(const int64_t* ids, const double* feat, const double* Rt, const double* cam, int n_frames,
+                                int max_kp, int first_frame, long long n_ids, int* frame_base, int* count,
+                                int* obs_frame, int64_t* obs_id, double* obs_meas, int64_t* lm_first, double* lm_point) {
+  if (!ids || !feat || !Rt || !cam || !frame_base || !count || !obs_frame || !obs_id || !obs_meas || !lm_first ||
+      !lm_point || n_frames < 0 || max_kp < 1 || first_frame < 0 || n_ids < 0)
+    return VUS_E_INVALID;
+  for (long long j = 0; j < n_ids; ++j) lm_first[j] = -1;
+  int n = 0;
+  for (int f = 0; f < n_frames; ++f) {
+    frame_base[f] = n;
+    if (f < first_frame) continue;
+    for (int i = 0; i < max_kp; ++i) {
+      int64_t id = ids[(size_t)f * max_kp + i];
+      if (id < 0 || id >= n_ids) continue;
+      double tri[6];
+      int rc = vus_triangulate_cpu(feat + ((size_t)f * max_kp + i) * 4, 1, cam, Rt + 12 * (size_t)f, tri); /* :265 */
+      if (rc) return rc;
+      if (lm_first[id] < 0) {                       /* :297 `not initial_estimate.exists(L(id))` */
+        lm_first[id] = (int64_t)f * max_kp + i;
+        lm_point[3 * id] = tri[0]; lm_point[3 * id + 1] = tri[1]; lm_point[3 * id + 2] = tri[2];   /* :298 */
+      }
+      obs_frame[n] = f;                             /* :300-305 */
+      obs_id[n] = id;
+      obs_meas[3 * (size_t)n] = tri[3]; obs_meas[3 * (size_t)n + 1] = tri[4]; obs_meas[3 * (size_t)n + 2] = tri[5];
+      ++n;
+    }
+  }
+  frame_base[n_frames] = n;
+  count[0] = n;
+  return VUS_OK;
+}
+
+/* GenericStereoFactor3D's h(X, L) - z at the initial estimate, unwhitened (gtsam StereoCamera::project; the same
+ * projection as the BA oracle's stereo factor, vus_oracle_ba.c). */
+int vus_stereo_initial_residuals_cpu(const double* Rt, const double* K, const double* lm_point, const int* obs_frame,
+                                     const int64_t* obs_id, const double* obs_meas, int n, double* resid) {
+  if (n < 0 || (n > 0 && (!Rt || !K || !lm_point || !obs_frame || !obs_id || !obs_meas || !resid))) return VUS_E_INVALID;
+  double fx = K[0], fy = K[1], cx = K[3], cy = K[4], b = K[5];
+  for (int a = 0; a < n; ++a) {
+    const double* T = Rt + 12 * (size_t)obs_frame[a];
+    const double* p = lm_point + 3 * (size_t)obs_id[a];
+    double d0 = p[0] - T[9], d1 = p[1] - T[10], d2 = p[2] - T[11];
+    double x = (T[0] * d0 + T[3] * d1) + T[6] * d2;
+    double y = (T[1] * d0 + T[4] * d1) + T[7] * d2;
+    double z = (T[2] * d0 + T[5] * d1) + T[8] * d2;
+    double* r = resid + 3 * (size_t)a;
+    if (!(z > 0.0)) { r[0] = r[1] = r[2] = HUGE_VAL; continue; }
+    r[0] = (cx + fx * x / z) - obs_meas[3 * (size_t)a];
+    r[1] = (cx + fx * (x - b) / z) - obs_meas[3 * (size_t)a + 1];
+    r[2] = (cy + fy * y / z) - obs_meas[3 * (size_t)a + 2];
+  }
+  return VUS_OK;
+}

@@ -24,6 +24,8 @@ SIGNATURES = {
     "vus_pyramid_append": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P,
                            _P],
     "vus_track_ids": [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P],
+    "vus_stereo_initial_residuals": [_P, _P, _P, _P, _P, _P, c_int, _P, _P],
+    "vus_emit_stereo_factors": [_P, _P, _P, _P, c_int, c_int, c_int, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P],
     # bundle adjustment (struct arguments are passed by address)
     "vus_ba_linearize": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "vus_ba_structure_count": [_P, c_int, _P, _P, _P],

@@ -957,6 +957,164 @@ __global__ void triangulate_kernel(const double* __restrict__ feat, int n, const
   out[6 * i + 5] = v;
 }
 
+// ---------------------------------------------------------------------------------------------
+// vus_emit_stereo_factors: the reference's per-keyframe Python loops (get_landmarks per feature, batch.py:149-176; the
+// landmark loop of batch_create, batch.py:295-305) for all keyframes at once.
+__device__ __forceinline__ void triangulate_one(const double* __restrict__ ft, const double* __restrict__ cam,
+                                                const double* __restrict__ Rt, double* out) {
+  const double fx = cam[0], fy = cam[1], cx = cam[2], cy = cam[3], baseline = cam[4];
+  const double res_x = cam[5], res_y = cam[6];
+  const double f = (fx + fy) / 2.0;
+  const double uL = (ft[0] + 1) * 0.5 * res_x;
+  const double uR = (ft[2] + 1) * 0.5 * res_x;
+  const double v = ((ft[1] + ft[3]) / 2.0 + 1) * 0.5 * res_y;
+  const double d = uR - uL;
+  const double Wd = d / baseline;
+  const double xc = (uL - cx) / Wd, yc = (v - cy) / Wd, zc = f / Wd;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) out[r] = ((Rt[3 * r + 0] * xc + Rt[3 * r + 1] * yc) + Rt[3 * r + 2] * zc) + Rt[9 + r];
+  out[3] = uL;
+  out[4] = uR;
+  out[5] = v;
+}
+
+constexpr int EMIT_THREADS = 256;
+
+// pass 1 (one workgroup per keyframe): features per keyframe; first sighting of every id (atomicMin of f * max_kp + i)
+__global__ __launch_bounds__(EMIT_THREADS) void emit_count_kernel(const long long* __restrict__ ids, int max_kp,
+                                                                  int first_frame, long long n_ids,
+                                                                  int* __restrict__ frame_count,
+                                                                  unsigned long long* __restrict__ lm_first) {
+  __shared__ int s_n;
+  const int f = blockIdx.x;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  int local = 0;
+  if (f >= first_frame)
+    for (int i = threadIdx.x; i < max_kp; i += EMIT_THREADS) {
+      const long long id = ids[(size_t)f * max_kp + i];
+      if (id >= 0 && id < n_ids) {
+        ++local;
+        atomicMin(&lm_first[id], (unsigned long long)f * (unsigned long long)max_kp + (unsigned long long)i);
+      }
+    }
+  atomicAdd(&s_n, local);
+  __syncthreads();
+  if (threadIdx.x == 0) frame_count[f] = s_n;
+}
+
+// exclusive prefix sum of the per-keyframe counts (one workgroup; n_frames is a few thousand at most)
+__global__ __launch_bounds__(1024) void emit_scan_kernel(int* __restrict__ frame_base, int n_frames, int* __restrict__ count) {
+  __shared__ int s_part[1024];
+  const int tid = threadIdx.x;
+  const int per = (n_frames + 1023) / 1024;
+  int local = 0;
+  for (int u = 0; u < per; ++u) {
+    const int f = tid * per + u;
+    if (f < n_frames) local += frame_base[f];
+  }
+  s_part[tid] = local;
+  __syncthreads();
+  for (int o = 1; o < 1024; o <<= 1) {
+    const int v = tid >= o ? s_part[tid - o] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int run = s_part[tid] - local;
+  for (int u = 0; u < per; ++u) {
+    const int f = tid * per + u;
+    if (f < n_frames) {
+      const int c = frame_base[f];
+      frame_base[f] = run;
+      run += c;
+    }
+  }
+  if (tid == 1023) {
+    frame_base[n_frames] = s_part[1023];
+    count[0] = s_part[1023];
+  }
+}
+
+// pass 2 (one workgroup per keyframe): ordered compaction of the keyframe's features behind frame_base[f]
+__global__ __launch_bounds__(EMIT_THREADS) void emit_write_kernel(const long long* __restrict__ ids,
+                                                                  const double* __restrict__ feat,
+                                                                  const double* __restrict__ Rt,
+                                                                  const double* __restrict__ cam, int max_kp,
+                                                                  int first_frame, long long n_ids,
+                                                                  const int* __restrict__ frame_base,
+                                                                  int* __restrict__ obs_frame,
+                                                                  long long* __restrict__ obs_id,
+                                                                  double* __restrict__ obs_meas,
+                                                                  long long* __restrict__ lm_first,
+                                                                  double* __restrict__ lm_point) {
+  __shared__ int s_part[EMIT_THREADS];
+  const int f = blockIdx.x, tid = threadIdx.x;
+  if (f < first_frame) return;
+  const int per = (max_kp + EMIT_THREADS - 1) / EMIT_THREADS;      // consecutive slots per thread
+  int local = 0;
+  for (int u = 0; u < per; ++u) {
+    const int i = tid * per + u;
+    if (i < max_kp) {
+      const long long id = ids[(size_t)f * max_kp + i];
+      local += (id >= 0 && id < n_ids) ? 1 : 0;
+    }
+  }
+  s_part[tid] = local;
+  __syncthreads();
+  for (int o = 1; o < EMIT_THREADS; o <<= 1) {
+    const int v = tid >= o ? s_part[tid - o] : 0;
+    __syncthreads();
+    s_part[tid] += v;
+    __syncthreads();
+  }
+  int pos = frame_base[f] + s_part[tid] - local;
+  for (int u = 0; u < per; ++u) {
+    const int i = tid * per + u;
+    if (i >= max_kp) break;
+    const long long id = ids[(size_t)f * max_kp + i];
+    if (id < 0 || id >= n_ids) continue;
+    double tri[6];
+    triangulate_one(feat + ((size_t)f * max_kp + i) * 4, cam, Rt + 12 * (size_t)f, tri);
+    obs_frame[pos] = f;
+    obs_id[pos] = id;
+    obs_meas[3 * (size_t)pos] = tri[3];
+    obs_meas[3 * (size_t)pos + 1] = tri[4];
+    obs_meas[3 * (size_t)pos + 2] = tri[5];
+    if (lm_first[id] == (long long)f * max_kp + i) {      // batch.py:297-298: the first sighting initialises L(id)
+      lm_point[3 * (size_t)id] = tri[0];
+      lm_point[3 * (size_t)id + 1] = tri[1];
+      lm_point[3 * (size_t)id + 2] = tri[2];
+    }
+    ++pos;
+  }
+}
+
+// h(X, L) - z of gtsam's GenericStereoFactor3D (StereoCamera::project: q = R^T (p - t), uL = cx + fx x / z,
+// uR = cx + fx (x - b) / z, v = cy + fy y / z), unwhitened, one factor per thread; statement order = the oracle's
+__global__ void stereo_initial_residuals_kernel(const double* __restrict__ Rt, const double* __restrict__ K,
+                                                const double* __restrict__ lm_point, const int* __restrict__ obs_frame,
+                                                const long long* __restrict__ obs_id, const double* __restrict__ obs_meas,
+                                                int n, double* __restrict__ resid) {
+  const int a = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a >= n) return;
+  const double* T = Rt + 12 * (size_t)obs_frame[a];
+  const double* p = lm_point + 3 * (size_t)obs_id[a];
+  const double fx = K[0], fy = K[1], cx = K[3], cy = K[4], b = K[5];
+  const double d0 = p[0] - T[9], d1 = p[1] - T[10], d2 = p[2] - T[11];
+  const double x = (T[0] * d0 + T[3] * d1) + T[6] * d2;
+  const double y = (T[1] * d0 + T[4] * d1) + T[7] * d2;
+  const double z = (T[2] * d0 + T[5] * d1) + T[8] * d2;
+  double* r = resid + 3 * (size_t)a;
+  if (!(z > 0.0)) {
+    r[0] = r[1] = r[2] = __builtin_huge_val();
+    return;
+  }
+  r[0] = (cx + fx * x / z) - obs_meas[3 * (size_t)a];
+  r[1] = (cx + fx * (x - b) / z) - obs_meas[3 * (size_t)a + 1];
+  r[2] = (cy + fy * y / z) - obs_meas[3 * (size_t)a + 2];
+}
+
 int check_image_args(const void* img, int n_img, int H, int W, int pitch) {
   VUS_REQUIRE(img != nullptr, "image pointer is null");
   VUS_REQUIRE(n_img >= 0 && n_img <= (1 << 20), "n_img=%d out of range [0, 2^20]", n_img);
@@ -1426,6 +1584,45 @@ extern "C" int vus_track_ids(const int32_t* stereo_idx, const int32_t* track_idx
       stereo_idx, track_idx, kp_keys, kp_count, n_frames, max_kp, H, W, reinterpret_cast<long long*>(ids_out), feat_out,
       reinterpret_cast<long long*>(n_ids_out));
   VUS_CHECK_LAUNCH("track_ids");
+  return VUS_OK;
+}
+
+extern "C" int vus_emit_stereo_factors(const int64_t* ids, const double* feat, const double* Rt, const double* cam,
+                                       int n_frames, int max_kp, int first_frame, long long n_ids, int* frame_base,
+                                       int* count, int* obs_frame, int64_t* obs_id, double* obs_meas, int64_t* lm_first,
+                                       double* lm_point, void* stream) {
+  VUS_REQUIRE(ids && feat && Rt && cam && frame_base && count && lm_first && lm_point, "null buffer");
+  VUS_REQUIRE(obs_frame && obs_id && obs_meas, "null output buffer");
+  VUS_REQUIRE(n_frames >= 0 && n_frames <= 65535 && max_kp >= 1 && first_frame >= 0 && n_ids >= 0,
+              "n_frames=%d max_kp=%d first_frame=%d n_ids=%lld", n_frames, max_kp, first_frame, n_ids);
+  VUS_REQUIRE((long long)n_frames * max_kp < (1ll << 31), "n_frames * max_kp overflows the int32 factor index");
+  hipStream_t st = vus::as_stream(stream);
+  if (n_ids > 0) VUS_CHECK_HIP(hipMemsetAsync(lm_first, 0xFF, sizeof(int64_t) * (size_t)n_ids, st));   // = -1 = UINT64_MAX
+  if (n_frames == 0) {
+    VUS_CHECK_HIP(hipMemsetAsync(count, 0, sizeof(int), st));
+    VUS_CHECK_HIP(hipMemsetAsync(frame_base, 0, sizeof(int), st));
+    return VUS_OK;
+  }
+  emit_count_kernel<<<n_frames, EMIT_THREADS, 0, st>>>(reinterpret_cast<const long long*>(ids), max_kp, first_frame, n_ids,
+                                                        frame_base, reinterpret_cast<unsigned long long*>(lm_first));
+  emit_scan_kernel<<<1, 1024, 0, st>>>(frame_base, n_frames, count);
+  emit_write_kernel<<<n_frames, EMIT_THREADS, 0, st>>>(reinterpret_cast<const long long*>(ids), feat, Rt, cam, max_kp,
+                                                        first_frame, n_ids, frame_base, obs_frame,
+                                                        reinterpret_cast<long long*>(obs_id), obs_meas,
+                                                        reinterpret_cast<long long*>(lm_first), lm_point);
+  VUS_CHECK_LAUNCH("emit_stereo_factors");
+  return VUS_OK;
+}
+
+extern "C" int vus_stereo_initial_residuals(const double* Rt, const double* K, const double* lm_point,
+                                            const int* obs_frame, const int64_t* obs_id, const double* obs_meas, int n,
+                                            double* resid, void* stream) {
+  VUS_REQUIRE(n >= 0, "n=%d", n);
+  if (n == 0) return VUS_OK;
+  VUS_REQUIRE(Rt && K && lm_point && obs_frame && obs_id && obs_meas && resid, "null buffer");
+  stereo_initial_residuals_kernel<<<(n + 255) / 256, 256, 0, vus::as_stream(stream)>>>(
+      Rt, K, lm_point, obs_frame, reinterpret_cast<const long long*>(obs_id), obs_meas, n, resid);
+  VUS_CHECK_LAUNCH("stereo_initial_residuals");
   return VUS_OK;
 }
 

@@ -281,6 +281,33 @@ class StereoOrbFrontend:
                   _lib.current_stream_ptr())
         return ids, feats, int(n_ids.item())
 
+    def stereo_factors(self, ids: torch.Tensor, feats: torch.Tensor, n_ids: int, Rt: torch.Tensor, cam: torch.Tensor,
+                       first_frame: int = 1):
+        """What the reference's Python loops make of the CameraMeasurement stream, for all keyframes in two launches
+        (vus_emit_stereo_factors): get_landmarks for every feature of every keyframe (batch.py:264-265, 144-176) and
+        the landmark loop of batch_create (batch.py:295-305; keyframe 0 has none, hence first_frame = 1).
+        ids / feats / n_ids: feature_tracks()'s output; Rt f64 [F,12]: zed_world_transform per keyframe; cam f64 [8]
+        as for triangulate().  Returns a dict of device tensors: obs_frame int32 [n], obs_id int64 [n],
+        obs_meas f64 [n,3] (uL, uR, v) in batch_create's factor order; lm_first int64 [n_ids] (-1: id not seen in
+        keyframes >= first_frame), lm_point f64 [n_ids,3] (first-sighting world point = initial value of L(id))."""
+        F, K = ids.shape
+        dev = ids.device
+        assert Rt.shape == (F, 12) and Rt.dtype == torch.float64 and Rt.is_contiguous() and cam.numel() == 8
+        cap = F * K
+        base = torch.empty((F + 1,), dtype=torch.int32, device=dev)
+        count = torch.zeros((1,), dtype=torch.int32, device=dev)
+        of = torch.empty((cap,), dtype=torch.int32, device=dev)
+        oi = torch.empty((cap,), dtype=torch.int64, device=dev)
+        om = torch.empty((cap, 3), dtype=torch.float64, device=dev)
+        first = torch.empty((max(n_ids, 1),), dtype=torch.int64, device=dev)
+        pt = torch.zeros((max(n_ids, 1), 3), dtype=torch.float64, device=dev)
+        ptr = _lib.ptr
+        _lib.call("vus_emit_stereo_factors", ptr(ids), ptr(feats), ptr(Rt), ptr(cam), F, K, int(first_frame), int(n_ids),
+                  ptr(base), ptr(count), ptr(of), ptr(oi), ptr(om), ptr(first), ptr(pt), _lib.current_stream_ptr())
+        n = int(count.item())
+        return {"obs_frame": of[:n], "obs_id": oi[:n], "obs_meas": om[:n], "lm_first": first[:n_ids],
+                "lm_point": pt[:n_ids]}
+
     def camera_measurements(self, res: FrontendResult) -> List[CameraMeasurement]:
         """Per frame, the published features as CameraMeasurement records (message shape of
         batch.py:149-154), built from feature_tracks()."""

@@ -222,7 +222,7 @@ IMU_ACC_COV, IMU_GYRO_COV, IMU_INT_COV = 8.999999999999999e-08, 1.21846967914683
 
 
 def nav_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, kf_period=0.2, pose_sigma_t=0.05, pose_sigma_r=0.01,
-                 meas_sigma=1.0, dvl_sigma=0.0):
+                 meas_sigma=1.0, dvl_sigma=0.0, rest_start=False):
     """Down-looking stereo rig on a smooth meandering track with a 200 Hz IMU (dt = 0.005, batch.py:290)
     and a DVL (body-frame velocity).  The keyframe states are produced by integrating the sampled IMU
     signals with the same discrete model the preintegration uses, so the inertial factors are exactly
@@ -243,7 +243,11 @@ def nav_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, kf_period=0.2, pose_sigma_t=
         Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
         Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
         Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
-        p = np.array([1.25 * t, 1.5 * np.sin(0.2 * t), 0.15 * np.sin(0.3 * t)])
+        if rest_start:      # the vehicle starts from rest, as batch.py:282's zero-velocity prior on V(0) assumes
+            p = np.array([1.25 * (t - 1.5 * (1.0 - np.exp(-t / 1.5))), 1.5 * (1.0 - np.cos(0.2 * t)),
+                          0.15 * (1.0 - np.cos(0.3 * t))])
+        else:
+            p = np.array([1.25 * t, 1.5 * np.sin(0.2 * t), 0.15 * np.sin(0.3 * t)])
         return Rz @ Ry @ Rx @ R0, p
 
     def derivs(t, h=1e-4):
@@ -325,3 +329,70 @@ def nav_sequence(n_kf, n_lm, obs_per_kf, seed=SEED, kf_period=0.2, pose_sigma_t=
         "obs_pose": obs_p.astype(np.int32), "obs_point": obs_l.astype(np.int32), "meas": meas,
         "K": np.array([fx, fy, 0.0, cx, cy, BASELINE_M]), "sigma": STEREO_SIGMA, "prior_sigmas": np.array(PRIOR_SIGMAS),
     }
+
+
+# ---------------------------------------------------------------------------------------------
+# A RENDERED scene: the end-to-end sequence of the north star (images -> front-end -> feature tracks ->
+# get_landmarks -> batch_create -> LM; /root/reference/batch.py:144-176, 253-266, 270-305, 337).
+# A textured sea floor (the plane z = SCENE_PLANE_Z of the world frame, random 26-mm blocks: corner-rich like the
+# canvas above) seen by the down-looking rectified stereo rig of nav_sequence(): every pixel is the intersection of its
+# viewing ray with the plane, so disparity, parallax and perspective are those of the real geometry.  The calibration
+# is the reference's (batch.py:111, given for the 1920 x 1080 frame that get_landmarks' mapping u = (u0 + 1) / 2 * 1920
+# assumes, batch.py:116-117,152-154): pixel x of a W-pixel-wide image is the ray through u = x * 1920 / W.
+# Plain float64 multiply / add / divide / floor and the integer hash only: the same code under numpy and torch.
+SCENE_PLANE_Z = -4.0
+SCENE_TEXEL = 0.026
+
+
+def render_plane_view(T12, cam_offset_x, t, cam, H=720, W=1280, xp=np, device=None, seed=SEED):
+    """uint8 [H, W] view of the textured plane from the camera with pose T12 (row-major R then t, camera-to-world)
+    displaced by cam_offset_x along its own x axis (0 = left / cam0, the baseline = right / cam1).  `t`, `cam` key the
+    per-pixel sensor noise (uniform -4..4) like stereo_frames()."""
+    fx, fy, cx, cy = INTRINSIC
+    R = [float(v) for v in T12[:9]]
+    o = [float(T12[9 + r]) + R[3 * r] * float(cam_offset_x) for r in range(3)]
+    if xp is np:
+        xs = np.arange(W, dtype=np.float64)[None, :]
+        ys = np.arange(H, dtype=np.float64)[:, None]
+    else:
+        xs = xp.arange(W, dtype=xp.float64, device=device)[None, :]
+        ys = xp.arange(H, dtype=xp.float64, device=device)[:, None]
+    xn = (xs * (RES_X / W) - cx) / fx
+    yn = (ys * (RES_Y / H) - cy) / fy
+    dz = (xn * R[6] + yn * R[7]) + R[8]
+    lam = (SCENE_PLANE_Z - o[2]) / dz
+    px = ((xn * R[0] + yn * R[1]) + R[2]) * lam + o[0]
+    py = ((xn * R[3] + yn * R[4]) + R[5]) * lam + o[1]
+    if xp is np:
+        bx = np.floor(px / SCENE_TEXEL).astype(np.int64) + 32768
+        by = np.floor(py / SCENE_TEXEL).astype(np.int64) + 32768
+    else:
+        bx = xp.floor(px / SCENE_TEXEL).to(xp.int64) + 32768
+        by = xp.floor(py / SCENE_TEXEL).to(xp.int64) + 32768
+    base = _mix32((((bx & 0xFFFF) << 16) | (by & 0xFFFF)) ^ _mix32_scalar(seed ^ 0x5CE7E)) & 255
+    pix = _arange(xp, H, device)[:, None] * W + _arange(xp, W, device)[None, :]
+    k = _mix32_scalar(_mix32_scalar((seed + t) & _M) ^ (0x9E3779B9 * (cam + 1)))
+    img = base + (_mix32(pix ^ k) % 9 - 4)
+    img = img.clip(0, 255) if xp is np else img.clamp(0, 255)
+    return img.astype(np.uint8) if xp is np else img.to(xp.uint8)
+
+
+def scene_frames(poses, H=720, W=1280, xp=np, device=None, seed=SEED):
+    """Rectified stereo pairs uint8 [n, 2, H, W] of the plane from the camera poses [n, 12]."""
+    out = []
+    for t in range(len(poses)):
+        pair = [render_plane_view(poses[t], BASELINE_M * c, t, c, H, W, xp, device, seed) for c in (0, 1)]
+        out.append(np.stack(pair) if xp is np else xp.stack(pair))
+    return np.stack(out) if xp is np else xp.stack(out)
+
+
+def scene_sequence(n_kf, H=720, W=1280, seed=SEED, render=True, **nav_kw):
+    """nav_sequence()'s trajectory, IMU and DVL data plus the rendered stereo pair of every keyframe ("frames",
+    uint8 [n_kf, 2, H, W]).  The sequence's synthetic landmark observations are NOT used by the end-to-end chain: its
+    landmarks come out of the front-end."""
+    nav_kw.setdefault("rest_start", True)
+    s = nav_sequence(n_kf, 300, 12, seed=seed, **nav_kw)
+    s["image_size"] = (H, W)
+    if render:
+        s["frames"] = scene_frames(s["poses_gt"], H, W, seed=seed)
+    return s
