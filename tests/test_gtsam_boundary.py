@@ -261,3 +261,77 @@ def test_values_array_blocks_behave_like_individually_inserted_variables():
     pa, pb = _pack_graph(graph, full), _pack_graph(graph, b)
     for name in ("meas", "pose_idx", "lm_idx", "pose_keys", "lm_keys", "poses", "points"):
         assert np.array_equal(pa[name], pb[name]), name
+
+
+def test_values_store_single_insertions_column_wise():
+    """Values.insert(L(id), p) / insert(X(i), pose) (batch.py:283-298) append to growing flat arrays; dictionary
+    semantics (exists, at*, update, erase, copy independence, duplicate errors) are those of gtsam.Values."""
+    import visual_underwater_slam_amd.gtsam as gtsam
+    from visual_underwater_slam_amd.gtsam import Values, Pose3, Rot3
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import B, V, X, L
+    v = Values()
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(500, 3))
+    for j in rng.permutation(500):                                   # any insertion order
+        v.insert(L(int(j)), pts[j])
+    for i in range(7):
+        v.insert(X(i), Pose3(Rot3.Rz(0.1 * i), [i, 2 * i, 3 * i]))
+        v.insert(V(i), np.array([i, 0.0, -i]))
+    v.insert(B(0), gtsam.imuBias.ConstantBias())
+    v.insert(77, np.arange(6.0))                                      # a vector that is not a 3-vector stays an object
+    assert v.size() == 500 + 14 + 2 and len(v.keys()) == v.size() and v.keys() == sorted(v.keys())
+    assert np.array_equal(v.point3_block(L(0) + np.arange(500)), pts)  # bulk read of singly inserted landmarks
+    assert np.array_equal(v.atPoint3(L(17)), pts[17]) and v.atVector(V(3)).tolist() == [3.0, 0.0, -3.0]
+    assert v.atVector(77).tolist() == list(range(6)) and v.atPose3(X(2)).equals(Pose3(Rot3.Rz(0.2), [2, 4, 6]), 1e-15)
+    keys, tab = v._pose3_table()
+    assert keys.tolist() == [X(i) for i in range(7)] and tab[3, 9:].tolist() == [3.0, 6.0, 9.0]
+    with pytest.raises(RuntimeError, match="already exists"):
+        v.insert(L(5), np.zeros(3))
+    with pytest.raises(RuntimeError, match="does not hold what atPose3 asks for"):
+        v.pose3_block([L(5)])
+    with pytest.raises(RuntimeError, match="does not exist"):
+        v.point3_block([L(5), L(9999)])
+    w = Values(v)                                                     # copies do not share storage
+    w.update(L(5), [9.0, 9.0, 9.0]); w.erase(L(6)); w.insert(L(6), [1.0, 1.0, 1.0]); w.erase(X(6))
+    assert np.array_equal(v.atPoint3(L(5)), pts[5]) and np.array_equal(v.atPoint3(L(6)), pts[6]) and v.exists(X(6))
+    assert w.atPoint3(L(5)).tolist() == [9.0] * 3 and w.atPoint3(L(6)).tolist() == [1.0] * 3 and not w.exists(X(6))
+    assert w.size() == v.size() - 1 and w._pose3_table()[0].tolist() == [X(i) for i in range(6)]
+    got = w.point3_block(L(0) + np.arange(500))
+    exp = pts.copy(); exp[5] = 9.0; exp[6] = 1.0
+    assert np.array_equal(got, exp)
+    w._store_rows("point3", L(0) + np.arange(500), -pts)              # the optimizer's write-back
+    assert np.array_equal(w.atPoint3(L(123)), -pts[123])
+    with pytest.raises(RuntimeError, match="holds a"):
+        w.update(L(5), Pose3())
+    w.update(77, np.zeros(3))                                         # an object-held value may change freely
+    assert w.atVector(77).tolist() == [0.0] * 3
+
+
+def test_graph_records_stereo_factors_column_wise_and_packs_without_visiting_them():
+    import visual_underwater_slam_amd.gtsam as gtsam
+    from visual_underwater_slam_amd.gtsam.optimizer import _pack_graph
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import X, L
+    seq = synth.ba_sequence(8, 60, 20)
+    K = gtsam.Cal3_S2Stereo(*seq["K"])
+    noise = gtsam.noiseModel.Isotropic.Sigma(3, 10.0)
+    g, v = gtsam.NonlinearFactorGraph(), gtsam.Values()
+    g.add(gtsam.PriorFactorPose3(X(0), gtsam.Pose3.from_flat12(seq["poses_init"][0]),
+                                 gtsam.noiseModel.Diagonal.Sigmas(seq["prior_sigmas"])))
+    for i in range(8):
+        v.insert(X(i), gtsam.Pose3.from_flat12(seq["poses_init"][i]))
+    for a in range(len(seq["obs_pose"])):
+        lid = int(seq["obs_point"][a])
+        if not v.exists(L(lid)):
+            v.insert(L(lid), seq["points_init"][lid])
+        g.push_back(gtsam.GenericStereoFactor3D(gtsam.StereoPoint2(*seq["meas"][a]), noise, X(int(seq["obs_pose"][a])), L(lid), K))
+    n = len(seq["obs_pose"])
+    assert g.size() == n + 1 == g.nrFactors() and len(g._other) == 1 and g.at(5).keys() == [X(int(seq["obs_pose"][4])), L(int(seq["obs_point"][4]))]
+    pg = _pack_graph(g, v)
+    assert np.array_equal(pg["meas"], seq["meas"]) and np.array_equal(pg["pose_idx"], seq["obs_pose"])
+    assert np.array_equal(pg["lm_idx"], seq["obs_point"]) and np.array_equal(pg["points"], seq["points_init"])
+    g.push_back(gtsam.GenericStereoFactor3D(gtsam.StereoPoint2(1, 2, 3), gtsam.noiseModel.Isotropic.Sigma(3, 10.0), X(1), L(0), K))
+    assert len(_pack_graph(g, v)["meas"]) == n + 1                    # growing after a pack; an equal model is the same model
+    g.push_back(gtsam.GenericStereoFactor3D(gtsam.StereoPoint2(1, 2, 3), gtsam.noiseModel.Isotropic.Sigma(3, 5.0), X(2), L(0), K))
+    with pytest.raises(NotImplementedError, match="share one noise model"):
+        _pack_graph(g, v)
+    assert X(0) in g.keys() and L(0) in g.keys() and len(g.keys()) == 8 + len(seq["points_gt"])

@@ -19,6 +19,7 @@ Host-side classes here hold plain numpy values; no BA arithmetic happens in Pyth
 Errors surface as RuntimeError, as pybind11 does for gtsam's C++ exceptions.
 """
 import math
+from array import array
 from typing import Callable, Dict, List, Optional, Sequence
 
 import numpy as np
@@ -566,15 +567,89 @@ class _ValueBlock:
         return pos, self.keys[pos] == keys
 
 
+class _Slot:
+    """Dictionary entry of a variable whose value lives in one of the Values' growing columnar stores."""
+    __slots__ = ("kind", "row")
+
+    def __init__(self, kind, row):
+        self.kind, self.row = kind, row
+
+
+_WIDTH = {"point3": 3, "pose3": 12}
+
+
+class _Column:
+    """Growing columnar store of same-typed variables inserted ONE BY ONE (the way batch.py:283-298 inserts them):
+    keys and values are appended to flat C arrays at insertion time, so that packing a graph for the GPU, and writing
+    its result back, never loops over the variables in Python.  A sorted view (keys ascending -> row) is built lazily
+    and dropped by every insertion / erasure."""
+    __slots__ = ("kind", "width", "keys", "data", "dead", "_view")
+
+    def __init__(self, kind, other: Optional["_Column"] = None):
+        self.kind, self.width = kind, _WIDTH[kind]
+        self.keys = array("q", other.keys) if other is not None else array("q")
+        self.data = array("d", other.data) if other is not None else array("d")
+        self.dead = other.dead if other is not None else 0
+        self._view = None
+
+    def append(self, key, flat):
+        self.keys.append(key)
+        self.data.extend(flat)
+        self._view = None
+        return len(self.keys) - 1
+
+    def row(self, r):
+        w = self.width
+        return np.array(self.data[w * r:w * (r + 1)])
+
+    def set_row(self, r, flat):
+        w = self.width
+        self.data[w * r:w * (r + 1)] = array("d", flat)
+
+    def kill(self, r):
+        self.keys[r] = -1              # keys are symbols (chr << 56 | index) or plain non-negative integers
+        self.dead += 1
+        self._view = None
+
+    def arrays(self):
+        """(keys int64 [n], data f64 [n, width]) views of the live storage -- valid until the next append."""
+        k = np.frombuffer(self.keys, dtype=np.int64) if len(self.keys) else np.zeros(0, np.int64)
+        d = (np.frombuffer(self.data, dtype=np.float64) if len(self.data) else np.zeros(0)).reshape(-1, self.width)
+        return k, d
+
+    def view(self):
+        """(sorted live keys, their rows)."""
+        if self._view is None:
+            k, _ = self.arrays()
+            order = np.argsort(k, kind="stable")
+            if self.dead:
+                order = order[k[order] >= 0]
+            self._view = (k[order], order)
+        return self._view
+
+    def find(self, keys):
+        sk, rows = self.view()
+        if len(sk) == 0:
+            return np.zeros(len(keys), np.int64), np.zeros(len(keys), bool)
+        pos = np.minimum(np.searchsorted(sk, keys), len(sk) - 1)
+        return rows[pos], sk[pos] == keys
+
+    def __len__(self):
+        return len(self.keys) - self.dead
+
+
 class Values:
-    """gtsam.Values.  Variables inserted one by one (the way batch.py:274-298 does) live in a dict; the bulk
-    EXTENSION methods keep whole runs of Point3 / Pose3 variables as arrays, so that a graph with 50 000 landmarks
-    is packed for the GPU, and its result read back, without one Python object per variable."""
+    """gtsam.Values.  Storage is columnar from the moment of insertion: 3-vectors (Point3 landmarks, velocities) and
+    Pose3 values inserted one by one (batch.py:283-298) are appended to growing flat arrays (`_Column`), whole runs
+    inserted through the bulk EXTENSION methods are kept as arrays (`_ValueBlock`); only values of other types
+    (imuBias.ConstantBias, vectors of other sizes, Rot3) are held as objects.  Packing a 50 000-landmark graph for the
+    GPU and reading its result back therefore involve no per-variable Python work."""
 
     def __init__(self, other: Optional["Values"] = None):
         self._d: Dict[int, object] = dict(other._d) if other is not None else {}
         self._blk: List[_ValueBlock] = ([_ValueBlock(b.kind, b.keys, b.data.copy()) for b in other._blk]
                                         if other is not None else [])
+        self._col = {k: _Column(k, other._col[k] if other is not None else None) for k in _WIDTH}
 
     # -- block helpers ------------------------------------------------------------------------------
     def _find_block(self, key):
@@ -613,35 +688,35 @@ class Values:
 
     insert_points = insert_point3_block
 
+    def _stores(self, kind):
+        """Every array-backed store that can hold variables of `kind`: (find(keys) -> (rows, hit), data, kind)."""
+        for b in self._blk:
+            yield b.find, b.data, b.kind
+        for c in self._col.values():
+            if len(c):
+                yield c.find, c.arrays()[1], c.kind
+
     def _rows(self, kind, keys, what):
         """[n,w] array of the variables `keys` (int64 array) of the given kind; raises like gtsam's at*()."""
         keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(-1)
-        w = 3 if kind == "point3" else 12
-        out = np.empty((len(keys), w))
+        out = np.empty((len(keys), _WIDTH[kind]))
         todo = np.ones(len(keys), bool)
-        for b in self._blk:
-            pos, hit = b.find(keys)
+        for find, data, k in self._stores(kind):
+            pos, hit = find(keys)
             hit &= todo
             if hit.any():
-                if b.kind != kind:
-                    k = int(keys[np.nonzero(hit)[0][0]])
-                    raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(k)}\" does not hold what {what} asks for")
-                out[hit] = b.data[pos[hit]]
+                if k != kind:
+                    bad = int(keys[np.nonzero(hit)[0][0]])
+                    raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(bad)}\" does not hold what {what} asks for")
+                out[hit] = data[pos[hit]]
                 todo &= ~hit
-        for i in np.nonzero(todo)[0].tolist():
+        for i in np.nonzero(todo)[0].tolist():      # what is left is absent, or an object of another type
             k = int(keys[i])
             if k not in self._d:
                 raise RuntimeError(f"Attempting to at the key \"{symbol_shorthand.key_string(k)}\", "
                                    "which does not exist in the Values.")
-            v = self._d[k]
-            if kind == "pose3":
-                if not isinstance(v, Pose3):
-                    raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(k)}\" is not a Pose3")
-                out[i] = v.flat12()
-            else:
-                if not isinstance(v, np.ndarray) or v.size != 3:
-                    raise RuntimeError(f"landmark \"{symbol_shorthand.key_string(k)}\" is not a Point3")
-                out[i] = v
+            raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(k)}\" is not a "
+                               f"{'Pose3' if kind == 'pose3' else 'Point3'}")
         return out
 
     def point3_block(self, keys):
@@ -654,54 +729,72 @@ class Values:
 
     def _pose3_table(self):
         """(sorted keys, [n,12]) of every Pose3 variable."""
-        ks = [np.fromiter((k for k, v in self._d.items() if isinstance(v, Pose3)), np.int64)]
-        rows = [np.array([self._d[int(k)].flat12() for k in ks[0]]).reshape(-1, 12)]
+        sk, rows = self._col["pose3"].view()
+        ks, data = [sk], [self._col["pose3"].arrays()[1][rows]]
         for b in self._blk:
             if b.kind == "pose3":
-                ks.append(b.keys); rows.append(b.data)
-        keys, data = np.concatenate(ks), np.concatenate(rows)
+                ks.append(b.keys); data.append(b.data)
+        keys, data = np.concatenate(ks), np.concatenate(data)
         order = np.argsort(keys, kind="stable")
         return keys[order], data[order]
 
     def _store_rows(self, kind, keys, rows):
-        """Overwrite existing variables of `kind` (result write-back of the optimizer), vectorised for blocks."""
+        """Overwrite existing variables of `kind` (result write-back of the optimizer), vectorised."""
         keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(-1)
         todo = np.ones(len(keys), bool)
-        for b in self._blk:
-            if b.kind != kind:
+        for find, data, k in self._stores(kind):
+            if k != kind:
                 continue
-            pos, hit = b.find(keys)
+            pos, hit = find(keys)
             hit &= todo
-            b.data[pos[hit]] = rows[hit]
+            data[pos[hit]] = rows[hit]
             todo &= ~hit
-        for i in np.nonzero(todo)[0].tolist():
-            self._d[int(keys[i])] = Pose3.from_flat12(rows[i]) if kind == "pose3" else rows[i].copy()
+        if todo.any():
+            k = int(keys[np.nonzero(todo)[0][0]])
+            raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(k)}\" is not a stored "
+                               f"{'Pose3' if kind == 'pose3' else 'Point3'}")
 
     # -- gtsam API ---------------------------------------------------------------------------------
+    def _put(self, key, v):
+        if isinstance(v, Pose3):
+            self._d[key] = _Slot("pose3", self._col["pose3"].append(key, v.flat12()))
+        elif isinstance(v, np.ndarray) and v.size == 3:
+            self._d[key] = _Slot("point3", self._col["point3"].append(key, v))
+        else:
+            self._d[key] = v
+
     def insert(self, key, value):                                        # batch.py:274,283-288,298
         key = int(key)
-        if key in self._d or self._find_block(key)[0] is not None:
+        if key in self._d or (self._blk and self._find_block(key)[0] is not None):
             raise RuntimeError(f"Attempting to add a key-value pair with key \"{symbol_shorthand.key_string(key)}\", "
                                "which already exists in the Values.")
-        self._d[key] = self._coerce(value)
+        self._put(key, self._coerce(value))
 
     def update(self, key, value):
         key = int(key)
+        v = self._coerce(value)
         b, i = self._find_block(key)
+        held = b.kind if b is not None else None
+        if b is None:
+            if key not in self._d:
+                raise RuntimeError(f"Requested to update a key-value pair with key \"{symbol_shorthand.key_string(key)}\", "
+                                   "which does not exist in the Values.")
+            cur = self._d[key]
+            if not isinstance(cur, _Slot):       # an object-held value: replaced by whatever comes, as before
+                del self._d[key]
+                self._put(key, v)
+                return
+            held = cur.kind
+        # gtsam refuses to change a variable's type through update(): same RuntimeError as _at() / _rows()
+        ok = isinstance(v, Pose3) if held == "pose3" else (isinstance(v, np.ndarray) and v.size == 3)
+        if not ok:
+            raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(key)}\" holds a "
+                               f"{'Pose3' if held == 'pose3' else 'Point3'}, not the {type(v).__name__} update() was given")
+        flat = v.flat12() if held == "pose3" else v
         if b is not None:
-            v = self._coerce(value)
-            # gtsam refuses to change a variable's type through update(): same RuntimeError as _at() / _rows()
-            ok = isinstance(v, Pose3) if b.kind == "pose3" else (isinstance(v, np.ndarray) and v.size == 3)
-            if not ok:
-                held = "Pose3" if b.kind == "pose3" else "Point3"
-                raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(key)}\" holds a {held}, "
-                                   f"not the {type(v).__name__} update() was given")
-            b.data[i] = v.flat12() if b.kind == "pose3" else v
-            return
-        if key not in self._d:
-            raise RuntimeError(f"Requested to update a key-value pair with key \"{symbol_shorthand.key_string(key)}\", "
-                               "which does not exist in the Values.")
-        self._d[key] = self._coerce(value)
+            b.data[i] = flat
+        else:
+            self._col[held].set_row(self._d[key].row, flat)
 
     def insert_or_assign(self, key, value):
         if self.exists(key):
@@ -717,7 +810,7 @@ class Values:
 
     def exists(self, key):                                               # batch.py:60,297
         key = int(key)
-        return key in self._d or self._find_block(key)[0] is not None
+        return key in self._d or (bool(self._blk) and self._find_block(key)[0] is not None)
 
     def erase(self, key):
         key = int(key)
@@ -727,12 +820,17 @@ class Values:
             return
         if key not in self._d:
             raise RuntimeError(f"key \"{symbol_shorthand.key_string(key)}\" does not exist in the Values")
-        del self._d[key]
+        cur = self._d.pop(key)
+        if isinstance(cur, _Slot):
+            self._col[cur.kind].kill(cur.row)
 
     def _at(self, key, kind, name):
         key = int(key)
         if key in self._d:
             v = self._d[key]
+            if isinstance(v, _Slot):
+                r = self._col[v.kind].row(v.row)
+                v = Pose3.from_flat12(r) if v.kind == "pose3" else r
         else:
             b, i = self._find_block(key)
             if b is None:
@@ -773,28 +871,64 @@ class Values:
 
 
 class NonlinearFactorGraph:
+    """gtsam.NonlinearFactorGraph.  GenericStereoFactor3D factors are ALSO recorded column-wise at the moment they are
+    added (measurement, pose key, landmark key appended to flat arrays), so that the optimizer packs a graph of two
+    million such objects (batch.py:300-305 pushes one per observation) without visiting them again."""
+
     def __init__(self):
         self._factors: List[_Factor] = []
+        self._other: List[_Factor] = []          # everything that is not a single GenericStereoFactor3D
+        self._st_meas, self._st_pk, self._st_lk = array("d"), array("q"), array("q")
+        self._st_model = self._st_K = None       # the one noise model / calibration the stereo factors share ...
+        self._st_mixed = False                   # ... or the fact that they do not (refused at optimize())
+
+    def _record(self, factor):
+        self._factors.append(factor)
+        if type(factor) is GenericStereoFactor3D:
+            m, K = factor._model, factor._K
+            if self._st_model is None:
+                self._st_model, self._st_K = m, K
+            elif (m is not self._st_model and not np.array_equal(m._sigmas, self._st_model._sigmas)) or \
+                    (K is not self._st_K and not K.equals(self._st_K)):
+                self._st_mixed = True
+            self._st_meas.extend(factor._measured._m)
+            self._st_pk.append(factor._keys[0])
+            self._st_lk.append(factor._keys[1])
+        else:
+            self._other.append(factor)
 
     def add(self, factor):                                               # batch.py:281-282
-        self._factors.append(factor)
+        self._record(factor)
 
     def push_back(self, factor):                                         # batch.py:291,292,305
-        self._factors.append(factor)
+        self._record(factor)
+
+    def _stereo_columns(self):
+        """(meas [n,3], pose keys [n], landmark keys [n], model, K, mixed) of the single stereo factors, in graph order."""
+        n = len(self._st_pk)
+        if n == 0:
+            return np.zeros((0, 3)), np.zeros(0, np.int64), np.zeros(0, np.int64), None, None, False
+        # copies (46 MB at two million factors, ~10 ms): a numpy VIEW of the growing arrays would pin their buffers and
+        # make the next push_back fail with BufferError
+        return (np.frombuffer(self._st_meas, dtype=np.float64).reshape(n, 3).copy(),
+                np.frombuffer(self._st_pk, dtype=np.int64).copy(), np.frombuffer(self._st_lk, dtype=np.int64).copy(),
+                self._st_model, self._st_K, self._st_mixed)
 
     def size(self):
         return len(self._factors)
 
     def nrFactors(self):
-        return sum(f.size() if isinstance(f, StereoFactorBlock) else 1 for f in self._factors)
+        return sum(f.size() if isinstance(f, StereoFactorBlock) else 1 for f in self._other) + len(self._st_pk)
 
     def at(self, i):
         return self._factors[i]
 
     def keys(self):
         out = set()
-        for f in self._factors:
+        for f in self._other:
             out.update(f.keys())
+        out.update(self._st_pk.tolist())
+        out.update(self._st_lk.tolist())
         return sorted(out)
 
     def error(self, values: Values) -> float:

@@ -114,12 +114,13 @@ def _pack_graph(graph, values, device=None):
         elif s != model_sigma or not K.equals(calib):
             raise NotImplementedError("all stereo factors of one graph must share one noise model and one Cal3_S2Stereo")
 
-    for i in range(graph.size()):
-        f = graph.at(i)
+    # single GenericStereoFactor3D objects were recorded column-wise when they were added (NonlinearFactorGraph._record):
+    # only the O(#keyframes) other factors are visited here
+    for f in graph._other:
         if isinstance(f, StereoFactorBlock):
             check_model(f._model, f._K)
             meas.append(f.meas); pkeys.append(f.pose_keys); lkeys.append(f.landmark_keys)
-        elif isinstance(f, GenericStereoFactor3D):
+        elif isinstance(f, GenericStereoFactor3D):       # a subclass instance: not recorded column-wise
             check_model(f._model, f._K)
             single_m.append(f._measured._m); single_p.append(f._keys[0]); single_l.append(f._keys[1])
         elif isinstance(f, PriorFactorPose3):
@@ -137,6 +138,12 @@ def _pack_graph(graph, values, device=None):
                 "gtsam.DvlVelocityFactor(noise, V(i), X(i), measurement) instead")
         else:
             raise NotImplementedError(f"factor type {type(f).__name__} is not supported by the MI355X optimizer")
+    c_meas, c_pk, c_lk, c_model, c_K, c_mixed = graph._stereo_columns()
+    if len(c_pk):
+        if c_mixed:
+            raise NotImplementedError("all stereo factors of one graph must share one noise model and one Cal3_S2Stereo")
+        check_model(c_model, c_K)
+        meas.append(c_meas); pkeys.append(c_pk); lkeys.append(c_lk)
     if single_m:
         meas.append(np.asarray(single_m, dtype=float).reshape(-1, 3))
         pkeys.append(np.asarray(single_p, dtype=np.int64)); lkeys.append(np.asarray(single_l, dtype=np.int64))
@@ -328,14 +335,14 @@ class LevenbergMarquardtOptimizer:
         out = Values(self._initial)
         if nav:
             for k, v in zip(nav["vel_keys"], vels):
-                out._d[k] = v.copy()
+                out.update(k, v)
             if nav["bias_key"] is not None:
-                out._d[nav["bias_key"]] = _ConstantBias(bias[:3], bias[3:])
+                out.update(nav["bias_key"], _ConstantBias(bias[:3], bias[3:]))
         out._store_rows("pose3", pg["pose_keys"], poses)
         out._store_rows("point3", pg["lm_keys"], points)
         if aux is not None:
             for k, x in zip(aux.keys, aux.x):
-                out._d[k] = x.copy()
+                out.update(k, x)
         mark("read_back")
         if prof:
             rep.boundary_ms = {n: round(1e3 * (t - marks[i][1]), 3) for i, (n, t) in enumerate(marks[1:])}
