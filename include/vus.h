@@ -297,6 +297,31 @@ int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lamb
  * value = -(n_ranks-1)*lambda restores a single copy. */
 int vus_ba_add_diag(double* Sband, int n_poses, int band, double value, void* stream);
 
+/* ---- graph packing on the device (csrc/pack.hip): what batch_create leaves as lists of factor objects
+ * (batch.py:295-305) becomes the arrays of vus_ba_problem without a host pass ----
+ * `work`: vus_pack_work_bytes(n) bytes of device scratch for n keys / observations.
+ *
+ * vus_keys_to_indices: idx_out[i] = rank of keys[i] among the DISTINCT keys (ascending), uniq_out[0 .. n_unique) = those
+ *   keys, n_unique[0] their number (device).  Keys are gtsam keys (non-negative: chr << 56 | index).
+ * vus_lookup_keys: idx_out[i] = position of queries[i] in sorted_keys [m] (ascending, distinct), -1 if absent;
+ *   first_miss[0] = the smallest i that missed, 0x7F7F7F7F if none (device).
+ * vus_ba_pack_observations: rows (obs_pose[i], obs_point[i], meas[i]) in any order -> the L-order arrays (sorted by
+ *   point, then pose) meas_L / obs_pose_L / obs_point_L / point_ptr [n_points+1] / obs_ppos, the P-order arrays
+ *   pose_ptr [n_poses+1] / pobs_lidx, and perm (L-order row -> input row).  flags[0] (device): bit 0 = two factors
+ *   between the same pose and landmark, bit 1 = an index out of range.
+ * vus_exclusive_scan_i32: out[i] = in[0] + .. + in[i-1] for i <= n as 32-bit offsets, total[0] = the whole sum in
+ *   64 bits (so that the caller can refuse a sum the offsets cannot hold); n up to a few hundred thousand. */
+long long vus_pack_work_bytes(int n);
+int vus_keys_to_indices(const int64_t* keys, int n, int* idx_out, int64_t* uniq_out, int* n_unique, void* work,
+                        long long work_bytes, void* stream);
+int vus_lookup_keys(const int64_t* sorted_keys, int m, const int64_t* queries, int n, int* idx_out, int* first_miss,
+                    void* stream);
+int vus_ba_pack_observations(const int* obs_pose, const int* obs_point, const double* meas, int n_obs, int n_poses,
+                             int n_points, double* meas_L, int* obs_pose_L, int* obs_point_L, int* point_ptr,
+                             int* obs_ppos, int* pose_ptr, int* pobs_lidx, int* perm, int* flags, void* work,
+                             long long work_bytes, void* stream);
+int vus_exclusive_scan_i32(const int* in, int n, int* out, long long* total, void* stream);
+
 /* Solve S dp = -gs by block-band Cholesky; n_poses counts NODES.  Sband is overwritten by the factor L in
  * the solver's own layout: the 6x6 blocks left of the 8-node diagonal panels hold their transposes, and (bands of
  * 7 nodes and more) the diagonal panels themselves hold the INVERSE of their 48x48 factor block.

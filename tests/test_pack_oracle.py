@@ -1,0 +1,142 @@
+"""Graph packing (include/vus.h, csrc/pack.hip): the oracle twins against numpy on the CPU, the HIP kernels against both on
+the GPU.  What is packed is the reference's factor emission (/root/reference/batch.py:295-305): one stereo factor per
+observation with keys X(i), L(id) -> compact indices, L-order / P-order arrays of vus_ba_problem."""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from visual_underwater_slam_amd import ba_pack, synth
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def random_observations(rng, n_poses, n_points, n_obs):
+    keys = rng.choice(n_poses * n_points, size=n_obs, replace=False)
+    return (keys % n_poses).astype(np.int32), (keys // n_poses).astype(np.int32), rng.normal(size=(n_obs, 3))
+
+
+def oracle_pack(O, op, ol, meas, n_poses, n_points):
+    n = len(op)
+    out = dict(meas=np.zeros((n, 3)), obs_pose=np.zeros(n, np.int32), obs_point=np.zeros(n, np.int32),
+               point_ptr=np.zeros(n_points + 1, np.int32), obs_ppos=np.zeros(n, np.int32),
+               pose_ptr=np.zeros(n_poses + 1, np.int32), pobs_lidx=np.zeros(n, np.int32), perm=np.zeros(n, np.int32))
+    flags = np.zeros(1, np.int32)
+    rc = O.lib().vus_ba_pack_observations_cpu(_p(op), _p(ol), _p(np.ascontiguousarray(meas)), n, n_poses, n_points, _p(out["meas"]),
+                                              _p(out["obs_pose"]), _p(out["obs_point"]), _p(out["point_ptr"]), _p(out["obs_ppos"]),
+                                              _p(out["pose_ptr"]), _p(out["pobs_lidx"]), _p(out["perm"]), _p(flags), None,
+                                              ctypes.c_longlong(0))
+    assert rc == 0
+    return out, int(flags[0])
+
+
+@pytest.mark.parametrize("shape", [(7, 30, 90), (40, 400, 3000), (3, 1, 3), (5, 9, 0)])
+def test_oracle_pack_equals_the_torch_construction(oracle, shape):
+    n_poses, n_points, n_obs = shape
+    op, ol, meas = random_observations(np.random.default_rng(1), n_poses, n_points, n_obs)
+    got, flags = oracle_pack(oracle, op, ol, meas, n_poses, n_points)
+    ref = ba_pack.pack_observations(torch.from_numpy(op), torch.from_numpy(ol), torch.from_numpy(meas), n_poses, n_points)
+    assert flags == 0
+    for k in ("meas", "obs_pose", "obs_point", "point_ptr", "obs_ppos", "pose_ptr", "pobs_lidx", "perm"):
+        assert np.array_equal(got[k], ref[k].numpy()), k
+
+
+def test_oracle_pack_flags_duplicates_and_bad_indices(oracle):
+    op, ol = np.array([0, 1, 0], np.int32), np.array([2, 2, 2], np.int32)
+    assert oracle_pack(oracle, op, ol, np.zeros((3, 3)), 4, 5)[1] == 1
+    op, ol = np.array([0, 9], np.int32), np.array([2, 1], np.int32)
+    assert oracle_pack(oracle, op, ol, np.zeros((2, 3)), 4, 5)[1] & 2
+
+
+def test_oracle_key_maps_equal_numpy(oracle):
+    rng = np.random.default_rng(2)
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import L, X
+    keys = (L(0) + rng.integers(0, 500, size=3000)).astype(np.int64)
+    idx, uniq, n_u = np.zeros(3000, np.int32), np.zeros(3000, np.int64), np.zeros(1, np.int32)
+    assert oracle.lib().vus_keys_to_indices_cpu(_p(keys), 3000, _p(idx), _p(uniq), _p(n_u), None, ctypes.c_longlong(0)) == 0
+    u, inv = np.unique(keys, return_inverse=True)
+    assert int(n_u[0]) == len(u) and np.array_equal(uniq[:len(u)], u) and np.array_equal(idx, inv)
+    table = (X(0) + np.arange(0, 100, 2)).astype(np.int64)
+    q = (X(0) + rng.integers(0, 100, size=400)).astype(np.int64)
+    pos, miss = np.zeros(400, np.int32), np.zeros(1, np.int32)
+    assert oracle.lib().vus_lookup_keys_cpu(_p(table), len(table), _p(q), 400, _p(pos), _p(miss)) == 0
+    hit = (q - X(0)) % 2 == 0
+    assert np.array_equal(pos[hit], ((q[hit] - X(0)) // 2).astype(np.int32)) and (pos[~hit] == -1).all()
+    assert int(miss[0]) == int(np.nonzero(~hit)[0][0])
+    cnt = rng.integers(0, 1000, size=777).astype(np.int32)
+    out, tot = np.zeros(778, np.int32), np.zeros(1, np.int64)
+    assert oracle.lib().vus_exclusive_scan_i32_cpu(_p(cnt), 777, _p(out), _p(tot)) == 0
+    assert np.array_equal(out, np.concatenate([[0], np.cumsum(cnt)]).astype(np.int32)) and int(tot[0]) == int(cnt.sum())
+
+
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(7, 30, 90), (40, 400, 3000), (3, 1, 3), (2000, 50000, 200000), (5, 9, 0)])
+def test_device_pack_equals_oracle_and_torch(gpu, oracle, shape):
+    n_poses, n_points, n_obs = shape
+    op, ol, meas = random_observations(np.random.default_rng(3), n_poses, n_points, n_obs)
+    got = ba_pack.pack_observations_device(torch.from_numpy(op).cuda(), torch.from_numpy(ol).cuda(),
+                                           torch.from_numpy(meas).cuda(), n_poses, n_points)
+    exp, flags = oracle_pack(oracle, op, ol, meas, n_poses, n_points)
+    assert flags == 0
+    for k in ("meas", "obs_pose", "obs_point", "point_ptr", "obs_ppos", "pose_ptr", "pobs_lidx", "perm"):
+        assert np.array_equal(got[k].cpu().numpy(), exp[k]), k
+
+
+@pytest.mark.gpu
+def test_device_pack_refuses_duplicates_and_bad_indices(gpu):
+    d = lambda a, t: torch.tensor(a, dtype=t, device="cuda")
+    with pytest.raises(NotImplementedError, match="same pose and landmark"):
+        ba_pack.pack_observations_device(d([0, 1, 0], torch.int32), d([2, 2, 2], torch.int32), torch.zeros((3, 3), dtype=torch.float64, device="cuda"), 4, 5)
+    with pytest.raises(IndexError):
+        ba_pack.pack_observations_device(d([0, 9], torch.int32), d([2, 1], torch.int32), torch.zeros((2, 3), dtype=torch.float64, device="cuda"), 4, 5)
+
+
+@pytest.mark.gpu
+def test_device_key_maps_equal_numpy(gpu):
+    from visual_underwater_slam_amd import _lib
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import L, X
+    rng = np.random.default_rng(4)
+    lib = _lib.load()
+    for n, span in ((1, 1), (3000, 500), (400000, 48000)):
+        keys = (L(0) + rng.integers(0, span, size=n)).astype(np.int64)
+        dk = torch.from_numpy(keys).cuda()
+        idx = torch.empty(n, dtype=torch.int32, device="cuda"); uniq = torch.empty(n, dtype=torch.int64, device="cuda")
+        cnt = torch.empty(2, dtype=torch.int32, device="cuda")
+        nb = int(lib.vus_pack_work_bytes(n))
+        work = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        _lib.call("vus_keys_to_indices", dk.data_ptr(), n, idx.data_ptr(), uniq.data_ptr(), cnt.data_ptr(), work.data_ptr(), nb,
+                  _lib.current_stream_ptr())
+        u, inv = np.unique(keys, return_inverse=True)
+        assert int(cnt[0]) == len(u) and np.array_equal(uniq[:len(u)].cpu().numpy(), u) and np.array_equal(idx.cpu().numpy(), inv)
+    table = torch.from_numpy((X(0) + np.arange(0, 100, 2)).astype(np.int64)).cuda()
+    q = (X(0) + rng.integers(0, 100, size=400)).astype(np.int64)
+    pos = torch.empty(400, dtype=torch.int32, device="cuda"); miss = torch.empty(1, dtype=torch.int32, device="cuda")
+    _lib.call("vus_lookup_keys", table.data_ptr(), 50, torch.from_numpy(q).cuda().data_ptr(), 400, pos.data_ptr(), miss.data_ptr(),
+              _lib.current_stream_ptr())
+    hit = (q - X(0)) % 2 == 0
+    assert np.array_equal(pos.cpu().numpy()[hit], ((q[hit] - X(0)) // 2).astype(np.int32)) and (pos.cpu().numpy()[~hit] == -1).all()
+    assert int(miss[0]) == int(np.nonzero(~hit)[0][0])
+    c = torch.from_numpy(rng.integers(0, 100000, size=10000).astype(np.int32)).cuda()
+    out = torch.empty(10001, dtype=torch.int32, device="cuda"); tot = torch.empty(1, dtype=torch.int64, device="cuda")
+    _lib.call("vus_exclusive_scan_i32", c.data_ptr(), 10000, out.data_ptr(), tot.data_ptr(), _lib.current_stream_ptr())
+    ref = np.concatenate([[0], np.cumsum(c.cpu().numpy().astype(np.int64))])
+    assert np.array_equal(out.cpu().numpy().astype(np.int64), ref) and int(tot[0]) == int(ref[-1])
+
+
+@pytest.mark.gpu
+def test_missing_pose_key_is_reported_like_gtsam(gpu):
+    import visual_underwater_slam_amd.gtsam as gtsam
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import X, L
+    seq = synth.ba_sequence(6, 40, 20)
+    g, v = gtsam.NonlinearFactorGraph(), gtsam.Values()
+    for i in range(5):                                               # X(5) is observed but never inserted
+        v.insert(X(i), gtsam.Pose3.from_flat12(seq["poses_init"][i]))
+    v.insert_point3_block(L(0) + np.arange(len(seq["points_init"]), dtype=np.int64), seq["points_init"])
+    g.push_back(gtsam.StereoFactorBlock(seq["meas"], gtsam.noiseModel.Isotropic.Sigma(3, 10.0), X(0) + seq["obs_pose"].astype(np.int64),
+                                        L(0) + seq["obs_point"].astype(np.int64), gtsam.Cal3_S2Stereo(*seq["K"])))
+    with pytest.raises(RuntimeError, match='"x5", which does not exist'):
+        gtsam.LevenbergMarquardtOptimizer(g, v, gtsam.LevenbergMarquardtParams()).optimize()

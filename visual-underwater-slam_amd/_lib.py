@@ -39,6 +39,11 @@ SIGNATURES = {
     "vus_ba_band_solve_multi": [_P, c_int, c_int, _P, c_int, _P, _P],
     "vus_ba_band_solve_split": [_P, c_int, c_int, _P, _P, _P, _P, _P],
     "vus_ba_band_solve_multi_split": [_P, c_int, c_int, _P, c_int, _P, _P, _P],
+    # graph packing (csrc/pack.hip)
+    "vus_keys_to_indices": [_P, c_int, _P, _P, _P, _P, ctypes.c_longlong, _P],
+    "vus_lookup_keys": [_P, c_int, _P, c_int, _P, _P, _P],
+    "vus_ba_pack_observations": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _P],
+    "vus_exclusive_scan_i32": [_P, c_int, _P, _P, _P],
     # navigation factors
     "vus_nav_linearize": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
     "vus_nav_assemble": [c_int, c_int, c_double, _P, _P, _P, _P, _P, _P, _P],
@@ -82,6 +87,8 @@ def load():
     lib.vus_ba_work_doubles.restype = ctypes.c_longlong
     lib.vus_ba_band_solve_work_doubles.argtypes = [c_int, c_int, c_int]
     lib.vus_ba_band_solve_work_doubles.restype = ctypes.c_longlong
+    lib.vus_pack_work_bytes.argtypes = [c_int]
+    lib.vus_pack_work_bytes.restype = ctypes.c_longlong
     lib.vus_ba_get_tuning.argtypes = [c_int]
     lib.vus_ba_get_tuning.restype = c_int
     lib.vus_nav_work_doubles.argtypes = [_P]

@@ -79,10 +79,12 @@ def build_structure_device(pk):
     n_obs, nP = pk["n_obs"], pk["n_poses"]
     if n_obs == 0:
         return ba_pack.build_structure(pk)
-    op, pptr = pk["obs_pose"], pk["point_ptr"].to(torch.int64)
-    seen = pptr[1:] > pptr[:-1]
-    first, last = op[pptr[:-1][seen]], op[pptr[1:][seen] - 1]
-    band = int((last - first).max().item())
+    band = pk.get("band")
+    if band is None:
+        op, pptr = pk["obs_pose"], pk["point_ptr"].to(torch.int64)
+        seen = pptr[1:] > pptr[:-1]
+        first, last = op[pptr[:-1][seen]], op[pptr[1:][seen] - 1]
+        band = int((last - first).max().item())
     if band > STRUCTURE_MAX_BAND:
         return ba_pack.build_structure(pk)
     dev = op.device
@@ -93,12 +95,13 @@ def build_structure_device(pk):
     rows = torch.empty((2, nP), dtype=torch.int32, device=dev)
     st_ptr = _lib.current_stream_ptr()
     _lib.call("vus_ba_structure_count", ctypes.addressof(cp), band, p(rows[0]), p(rows[1]), st_ptr)
-    base = torch.zeros((2, nP + 1), dtype=torch.int64, device=dev)
-    torch.cumsum(rows, 1, out=base[:, 1:])
-    n_blocks, n_pairs = (int(v) for v in base[:, nP].tolist())
+    base = torch.empty((2, nP + 1), dtype=torch.int32, device=dev)
+    totals = torch.empty((2,), dtype=torch.int64, device=dev)
+    for q in range(2):      # row counts -> list offsets (csrc/pack.hip; no torch.cumsum: its first use costs ~15 ms)
+        _lib.call("vus_exclusive_scan_i32", p(rows[q]), nP, p(base[q]), p(totals[q:]), st_ptr)
+    n_blocks, n_pairs = (int(v) for v in totals.tolist())
     if n_pairs >= 2 ** 31:
         raise NotImplementedError(f"{n_pairs} co-observation pairs exceed the int32 pair index")
-    base = base.to(torch.int32)
     i32 = dict(dtype=torch.int32, device=dev)
     st = {"band": band, "n_blocks": n_blocks, "n_pairs": n_pairs, "blk_ptr": torch.empty(n_blocks + 1, **i32),
           "blk_i": torch.empty(n_blocks, **i32), "blk_k": torch.empty(n_blocks, **i32),
@@ -120,8 +123,12 @@ class StereoBAProblem:
 
         def to_dev(x, dt):
             return torch.as_tensor(x).to(device=dev, dtype=dt).contiguous()
-        pk = ba_pack.pack_observations(to_dev(obs_pose, torch.int64), to_dev(obs_point, torch.int64),
-                                       to_dev(meas, torch.float64), n_poses, n_points)
+        if dev.type == "cuda":      # csrc/pack.hip: sorts and index arrays without torch's index operators
+            pk = ba_pack.pack_observations_device(to_dev(obs_pose, torch.int32), to_dev(obs_point, torch.int32),
+                                                  to_dev(meas, torch.float64), n_poses, n_points)
+        else:
+            pk = ba_pack.pack_observations(to_dev(obs_pose, torch.int64), to_dev(obs_point, torch.int64),
+                                           to_dev(meas, torch.float64), n_poses, n_points)
         st = build_structure_device(pk)
         self.pk, self.st = pk, st
         self.device = dev

@@ -44,6 +44,37 @@ def pack_observations(obs_pose, obs_point, meas, n_poses, n_points):
     }
 
 
+def pack_observations_device(obs_pose, obs_point, meas, n_poses, n_points):
+    """pack_observations() by the kernels of csrc/pack.hip (vus_ba_pack_observations): same dict, same contents, for CUDA
+    tensors -- obs_pose / obs_point int32, meas [n_obs,3] float64, any row order.  No torch index operator is involved
+    (their lazily loaded code objects cost the first call of a process ~90 ms); one small device read at the end."""
+    from . import _lib
+    dev = obs_pose.device
+    n_obs = int(obs_pose.numel())
+    i32 = dict(dtype=torch.int32, device=dev)
+    obs_pose = obs_pose.to(torch.int32).contiguous()
+    obs_point = obs_point.to(torch.int32).contiguous()
+    meas = meas.to(torch.float64).contiguous()
+    out = {"n_poses": int(n_poses), "n_points": int(n_points), "n_obs": n_obs,
+           "meas": torch.empty((n_obs, 3), dtype=torch.float64, device=dev), "obs_pose": torch.empty(n_obs, **i32),
+           "obs_point": torch.empty(n_obs, **i32), "point_ptr": torch.empty(int(n_points) + 1, **i32),
+           "obs_ppos": torch.empty(n_obs, **i32), "pose_ptr": torch.empty(int(n_poses) + 1, **i32),
+           "pobs_lidx": torch.empty(n_obs, **i32), "perm": torch.empty(n_obs, **i32)}
+    flags = torch.empty(1, **i32)
+    nbytes = int(_lib.load().vus_pack_work_bytes(n_obs))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    p = _lib.ptr
+    _lib.call("vus_ba_pack_observations", p(obs_pose), p(obs_point), p(meas), n_obs, int(n_poses), int(n_points),
+              p(out["meas"]), p(out["obs_pose"]), p(out["obs_point"]), p(out["point_ptr"]), p(out["obs_ppos"]),
+              p(out["pose_ptr"]), p(out["pobs_lidx"]), p(out["perm"]), p(flags), p(work), nbytes, _lib.current_stream_ptr())
+    f = int(flags.item())
+    if f & 2:
+        raise IndexError("a stereo factor refers to a pose or landmark index outside the problem")
+    if f & 1:
+        raise NotImplementedError("two stereo factors between the same pose and landmark are not supported")
+    return out
+
+
 def build_structure(pk):
     """Non-zero blocks of the reduced camera system and, per block, the pairs of P-order slots that
     see a common point (vus_ba_structure)."""

@@ -888,68 +888,12 @@ __device__ unsigned long long g_tm[8];
 #define VUS_TMARK(n)
 #endif
 
-// Stage the panel's diagonal block and n_tiles (1 or 2) 48-row tiles of the panel columns in LDS (rows
-// past the window or left of the band are zero), then solve the tiles in place: X = A * L_D^-T.
-// Block forward substitution on the matrix cores, 16 columns at a time: with M_b = (16x16 diagonal
-// block b of L_D)^-1 and G_b = -M_b * L_D[row block b][columns < 16b] (written over L_D in LDS),
-//   X_b = [X_0 .. X_b-1] * G_b^T + A_b * M_b^T
-// is 4b + 4 steps of v_mfma_f64_16x16x4_f64 per 16-row tile.  A 16-row tile belongs to one wave from
-// start to end, so the three block steps need no workgroup barrier.
-__device__ __forceinline__ void stage_and_solve(const double* __restrict__ Sb, int band, int k0, int pb, int i_last,
-                                                int pose0_a, int pose0_b, int n_tiles, double* __restrict__ Xa,
-                                                double* __restrict__ Xb, double* __restrict__ sL,
-                                                double* __restrict__ sM, double* __restrict__ sInv) {
+// Inverse blocks of the panel's 48x48 factor L_D held in sL (row stride LDD, zeros above the diagonal; sInv = 1 / diagonal,
+// 1 for the rows of a short last panel): M_b = (16x16 diagonal block b)^-1 -> sM, G_b = -M_b * L_D[row block b][columns <
+// 16 b] written over L_D's blocks (1,0), (2,0), (2,1) in sL.  Called by all 256 threads behind a barrier; ends in one.
+__device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* __restrict__ sM,
+                                               const double* __restrict__ sInv) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  {
-    // items = (tile, scalar row lr, panel pose kk): 6 contiguous doubles each; tile 0 = the diagonal block.
-    // Every global load is in flight before the first LDS store.
-    constexpr int ITEMS = UT * PB;                 // per tile
-    constexpr int XU = (3 * ITEMS + 255) / 256;
-    d2a_t ld[XU][3];
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      const int item = tid + 256 * u;
-      const long long o_item = bandidx::stage_item(band, k0, pb, i_last, pose0_a, pose0_b, n_tiles, item);
-      const bool have = o_item >= 0;
-      const double* src = have ? Sb + o_item : Sb;
-      const d2a_t* s2 = reinterpret_cast<const d2a_t*>(src);
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        ld[u][c] = s2[have ? c : 0];
-        if (!have) ld[u][c] = d2a_t{0.0, 0.0};
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < XU; ++u) {
-      const int item = tid + 256 * u;
-      const int tile = (item >= ITEMS) + (item >= 2 * ITEMS);
-      const int e = item - ITEMS * tile;
-      const int lr = e >> 3, kk = e & 7;
-      if (item < (1 + n_tiles) * ITEMS) {
-        double v[6] = {ld[u][0].x, ld[u][0].y, ld[u][1].x, ld[u][1].y, ld[u][2].x, ld[u][2].y};
-        double* dst;
-        if (tile == 0) {
-          const int ii = lr / 6, rr = lr - 6 * ii;
-          dst = sL + lr * LDD + 6 * kk;
-          if (kk == ii) {   // strict upper part of the diagonal 6x6 block is not part of L
-            double d = 1.0;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) {
-              if (c == rr) d = v[c];
-              if (c > rr) v[c] = 0.0;
-            }
-            sInv[lr] = (ii < pb) ? 1.0 / d : 1.0;
-          }
-        } else {
-          dst = (tile == 1 ? Xa : Xb) + lr * ULD + 6 * kk;
-        }
-#pragma unroll
-        for (int c = 0; c < 6; ++c) dst[c] = v[c];
-      }
-    }
-  }
-  __syncthreads();
-  VUS_TMARK(1);
   // M_b = (16x16 diagonal block b)^-1 from its 8x8 quadrants:  [A 0; C B]^-1 = [A^-1 0; -B^-1 C A^-1  B^-1]
   if (tid < NB) {   // column n of the inverse of 8x8 diagonal block h by forward substitution (rows past nb: identity)
     const int h = tid >> 3, n = tid & 7;
@@ -1014,6 +958,16 @@ __device__ __forceinline__ void stage_and_solve(const double* __restrict__ Sb, i
   }
   __syncthreads();
   VUS_TMARK(3);
+}
+
+// X = A * L_D^-T for n_tiles (1 or 2) 48-row tiles staged row-major in Xa / Xb (row stride ULD), in place: block forward
+// substitution with the inverse blocks of block_inverses(),
+//   X_b = [X_0 .. X_b-1] * G_b^T + A_b * M_b^T   (4 b + 4 steps of v_mfma_f64_16x16x4_f64 per 16-row tile).
+// A 16-row tile belongs to one wave from start to end, so the three block steps need no workgroup barrier.  Ends in one.
+__device__ __forceinline__ void solve_rows(int n_tiles, double* __restrict__ Xa, double* __restrict__ Xb,
+                                           const double* __restrict__ sL, const double* __restrict__ sM) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int arow = lane & 15, kq = lane >> 4;
   // 16-row tiles: n_tiles * 3 of them, wave w takes tiles w and w + 4
   const int n16 = 3 * n_tiles;
   double* Xt0 = (wave < 3 ? Xa + 16 * wave * ULD : Xb);
@@ -1054,6 +1008,72 @@ __device__ __forceinline__ void stage_and_solve(const double* __restrict__ Sb, i
   }
   __syncthreads();
   VUS_TMARK(4);
+}
+
+// Stage the panel's diagonal block and n_tiles (1 or 2) 48-row tiles of the panel columns in LDS (rows
+// past the window or left of the band are zero), then solve the tiles in place: X = A * L_D^-T.
+// Block forward substitution on the matrix cores, 16 columns at a time: with M_b = (16x16 diagonal
+// block b of L_D)^-1 and G_b = -M_b * L_D[row block b][columns < 16b] (written over L_D in LDS),
+//   X_b = [X_0 .. X_b-1] * G_b^T + A_b * M_b^T
+// is 4b + 4 steps of v_mfma_f64_16x16x4_f64 per 16-row tile.  A 16-row tile belongs to one wave from
+// start to end, so the three block steps need no workgroup barrier.
+__device__ __forceinline__ void stage_and_solve(const double* __restrict__ Sb, int band, int k0, int pb, int i_last,
+                                                int pose0_a, int pose0_b, int n_tiles, double* __restrict__ Xa,
+                                                double* __restrict__ Xb, double* __restrict__ sL,
+                                                double* __restrict__ sM, double* __restrict__ sInv) {
+  const int tid = threadIdx.x;
+  {
+    // items = (tile, scalar row lr, panel pose kk): 6 contiguous doubles each; tile 0 = the diagonal block.
+    // Every global load is in flight before the first LDS store.
+    constexpr int ITEMS = UT * PB;                 // per tile
+    constexpr int XU = (3 * ITEMS + 255) / 256;
+    d2a_t ld[XU][3];
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int item = tid + 256 * u;
+      const long long o_item = bandidx::stage_item(band, k0, pb, i_last, pose0_a, pose0_b, n_tiles, item);
+      const bool have = o_item >= 0;
+      const double* src = have ? Sb + o_item : Sb;
+      const d2a_t* s2 = reinterpret_cast<const d2a_t*>(src);
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        ld[u][c] = s2[have ? c : 0];
+        if (!have) ld[u][c] = d2a_t{0.0, 0.0};
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < XU; ++u) {
+      const int item = tid + 256 * u;
+      const int tile = (item >= ITEMS) + (item >= 2 * ITEMS);
+      const int e = item - ITEMS * tile;
+      const int lr = e >> 3, kk = e & 7;
+      if (item < (1 + n_tiles) * ITEMS) {
+        double v[6] = {ld[u][0].x, ld[u][0].y, ld[u][1].x, ld[u][1].y, ld[u][2].x, ld[u][2].y};
+        double* dst;
+        if (tile == 0) {
+          const int ii = lr / 6, rr = lr - 6 * ii;
+          dst = sL + lr * LDD + 6 * kk;
+          if (kk == ii) {   // strict upper part of the diagonal 6x6 block is not part of L
+            double d = 1.0;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+              if (c == rr) d = v[c];
+              if (c > rr) v[c] = 0.0;
+            }
+            sInv[lr] = (ii < pb) ? 1.0 / d : 1.0;
+          }
+        } else {
+          dst = (tile == 1 ? Xa : Xb) + lr * ULD + 6 * kk;
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) dst[c] = v[c];
+      }
+    }
+  }
+  __syncthreads();
+  VUS_TMARK(1);
+  block_inverses(sL, sM, sInv);
+  solve_rows(n_tiles, Xa, Xb, sL, sM);
 }
 
 __global__ __launch_bounds__(256) void chol_trsm_update_kernel(BandSet S, int band, int k0, int n_update, int k0_prev,

@@ -157,18 +157,27 @@ def _pack_graph(graph, values, device=None):
     if len(pose_keys) == 0:
         raise RuntimeError("the Values hold no Pose3 variable")
     if device is not None:
+        # key -> index on the GPU by csrc/pack.hip (vus_keys_to_indices: radix sort of the landmark keys + ranks of the
+        # distinct ones; vus_lookup_keys: binary search in the pose table), not by torch.unique / searchsorted
         import torch
+        from .. import _lib
         dev = torch.device(device)
+        n = len(lkeys)
         lk, pk = torch.from_numpy(lkeys).to(dev), torch.from_numpy(pkeys).to(dev)
-        lm_keys_t, lm_idx = torch.unique(lk, return_inverse=True)
+        i32 = dict(dtype=torch.int32, device=dev)
+        lm_idx, pose_idx = torch.empty(n, **i32), torch.empty(n, **i32)
+        uniq = torch.empty(n, dtype=torch.int64, device=dev)
+        counters = torch.empty(2, **i32)                       # [n_unique, first_miss]
+        nbytes = int(_lib.load().vus_pack_work_bytes(n))
+        work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         pose_keys_t = torch.from_numpy(pose_keys).to(dev)
-        pose_idx = torch.searchsorted(pose_keys_t, pk)
-        hit = pose_keys_t[pose_idx.clamp(max=len(pose_keys) - 1)] == pk
-        if pk.numel() and not bool(hit.all()):
-            k = int(pk[~hit][0].item())
-            raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(k)}\", which does not exist in the Values.")
-        pose_idx, lm_idx = pose_idx.to(torch.int32), lm_idx.to(torch.int32)
-        lm_keys = lm_keys_t.cpu().numpy()
+        p, st = _lib.ptr, _lib.current_stream_ptr()
+        _lib.call("vus_keys_to_indices", p(lk), n, p(lm_idx), p(uniq), p(counters), p(work), nbytes, st)
+        _lib.call("vus_lookup_keys", p(pose_keys_t), len(pose_keys), p(pk), n, p(pose_idx), p(counters[1:]), st)
+        n_unique, miss = (int(v) for v in counters.tolist())
+        if n and miss != 0x7F7F7F7F:
+            raise RuntimeError(f"Attempting to at the key \"{_sym.key_string(int(pkeys[miss]))}\", which does not exist in the Values.")
+        lm_keys = uniq[:n_unique].cpu().numpy()
         meas = torch.from_numpy(meas).to(dev)
     else:
         lm_keys, lm_idx = np.unique(lkeys, return_inverse=True)
