@@ -360,7 +360,10 @@ int vus_ba_band_solve_multi_split(double* Sband, int n_nodes, int band, double* 
  * are read from the environment ONCE, when the library is loaded (VUS_BAND_MODE, VUS_CB_MAX_WG); afterwards only
  * vus_ba_set_tuning() changes them, process-wide.  Host-only calls, no device work.
  *   VUS_TUNE_BAND_MODE   how a panel step is issued: -1 automatic; 0 one fused launch per panel; 1 a TRSM + SYRK launch
- *                        pair per panel (two systems share every launch); 2 the same pair per system on two streams.
+ *                        pair per panel (two systems share every launch); 2 the same pair per system on two streams;
+ *                        3 the persistent window kernel (one launch for the whole chain; where it does not apply --
+ *                        bands under 16 poses or over ~240, the one-sided entry points without `work` -- the
+ *                        automatic choice among 0..2 is taken).
  *   VUS_TUNE_CB_MAX_WG   cap on the cooperating workgroups of the back-substitution (0 = from the occupancy query). */
 #define VUS_TUNE_BAND_MODE 0
 #define VUS_TUNE_CB_MAX_WG 1

@@ -116,6 +116,40 @@ void sweep_backsolve(Sweep& S, int n_solve) {
       }
   }
 }
+
+// chol_window_kernel: every tile a slot hosts at every step (birth load, hand-over and flush stores use win_scalar), the
+// solved rows it reads and writes (solved_item), and the slot schedule itself (one slot per live tile, the same for its
+// whole life).
+void sweep_window(Sweep& S, int n_elim) {
+  const int n = S.n, band = S.band;
+  if (band < 2 * PB) return;
+  const int NT = (n + PB - 1) / PB, D = (band + PB - 1) / PB, M = D + 1, n_slots = M * (M + 1) / 2;
+  const int NE = n_elim >= n ? NT : n_elim / PB;
+  std::vector<int> owner((size_t)NT * (D + 1), -1);
+  for (int p = 0; p <= NE; ++p) {
+    const int k0 = PB * p, pb = n - k0 < PB ? n - k0 : PB;
+    int i_last = k0 + pb - 1 + band;
+    if (i_last > n - 1) i_last = n - 1;
+    for (int slot = 0; slot < n_slots; ++slot) {
+      int hi, lo, I, J;
+      win_slot_pair(slot, hi, lo);
+      win_tile_of(hi, lo, M, p, I, J);
+      if (!(J >= p && I >= J && I - J <= D && I - D <= p)) { S.fail("win_tile_of: tile not live", 0, 0, p, slot, I * 1000 + J); continue; }
+      if (I >= NT) continue;
+      int& o = owner[(size_t)I * (D + 1) + (I - J)];
+      if (o >= 0 && o != slot) S.fail("win_tile_of: tile changes slot", 0, 0, p, slot, I * 1000 + J);
+      o = slot;
+      for (int Rr = 0; Rr < 48; ++Rr)
+        for (int Cc = 0; Cc < 48; ++Cc) {
+          const long long off = win_scalar(band, n, PB * I, PB * J, Rr, Cc);
+          S.touch("win_scalar", off, 1, p, slot, Rr * 48 + Cc);
+          S.expect("win_scalar", off, blk(band, PB * I + Rr / 6, PB * J + Cc / 6) + 6 * (Rr % 6) + Cc % 6, p, slot, Rr * 48 + Cc);
+        }
+      if (p < NE && I > p)
+        for (int item = 0; item < UTP * PB * 6; ++item) S.touch("solved_item/window", solved_item(band, k0, pb, i_last, PB * I, item), 6, p, slot, item);
+    }
+  }
+}
 }  // namespace
 
 // Returns the number of offsets that fell outside the band of (n, band) [0 = all good]; `touched` receives the number of
@@ -128,6 +162,7 @@ extern "C" long long bandidx_sweep(int n, int band, int n_elim, long long* touch
   S.buf.assign((size_t)S.total, 1.0);
   sweep_factor(S, n_elim);
   sweep_backsolve(S, n_elim < n ? n_elim : 0);
+  sweep_window(S, n_elim);
   if (touched) *touched = S.touched + (S.sink < 0 ? 1 : 0);
   if (msg) snprintf(msg, 256, "%s", S.first);
   return S.bad;

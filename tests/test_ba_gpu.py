@@ -298,14 +298,14 @@ def _random_band_system(rng, nP, B):
     return A, Sb
 
 
-@pytest.mark.parametrize("max_wg,mode", [(None, None), (3, None), (None, 0), (None, 1), (None, 2)])
+@pytest.mark.parametrize("max_wg,mode", [(None, None), (3, None), (None, 0), (None, 1), (None, 2), (None, 3)])
 def test_two_sided_band_solve_equals_dense_solve(gpu, oracle, band_tuning, max_wg, mode):
     """vus_ba_band_solve_split / _multi_split: elimination from both ends of the band + dense middle system.  Random
     SPD block bands of many shapes (middle exactly `band` poses or up to 15 more, band not a multiple of the panel,
     systems too short to split -> fallback) against numpy; also with several row groups per workgroup forced."""
     from visual_underwater_slam_amd import _lib
     # mode: None = automatic; 0 the fused launch per panel; 1 both halves share a TRSM + SYRK launch pair on one stream;
-    # 2 a launch pair per half on two streams
+    # 2 a launch pair per half on two streams; 3 the persistent window kernel (bands of 16 poses and more)
     band_tuning(band_mode=mode, cb_max_wg=max_wg)
     lib = _lib.load()
     rng = np.random.default_rng(11)

@@ -40,7 +40,8 @@ def sweep(lib, n, band, n_elim=None):
 # (n, band): band 0, narrower than a panel, one short of / exactly / past a panel, not a multiple of 8, n not a multiple
 # of 8, band = n - 1, and the shapes of the GPU tests
 SHAPES = [(1, 0), (5, 0), (30, 0), (9, 2), (23, 7), (17, 16), (40, 11), (97, 8), (64, 63), (131, 37), (57, 1), (33, 9),
-          (200, 90), (260, 17), (64, 20), (20, 3), (333, 41), (41, 40), (48, 6), (49, 7), (50, 8), (120, 10)]
+          (200, 90), (260, 17), (64, 20), (20, 3), (333, 41), (41, 40), (48, 6), (49, 7), (50, 8), (120, 10),
+          (100, 16), (101, 23), (77, 24), (300, 224)]
 
 
 @pytest.mark.parametrize("n,band", SHAPES)

@@ -723,11 +723,15 @@ __device__ __forceinline__ void panel_update(double (&blk)[6], const double (&xr
 // LDS by the workgroup that has just produced them (fused launch) instead of being re-read from memory;
 // only the first lds_poses poses of the panel were touched by that update (bands narrower than a panel),
 // the rest still comes from memory.
-template <bool FROM_LDS>
+// PUBLISH (persistent window kernel): the factor and the solved right-hand sides leave the workgroup with agent-scope
+// (sc1) stores, because workgroups of the SAME launch read them; lds_out / lds_rhs_out also receive the factor (row
+// stride LDD, zeros above the diagonal) and the solved right-hand-side rows (row stride NB) for the caller's next phase.
+template <bool FROM_LDS, bool PUBLISH = false>
 __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, int k0, double* yv, size_t ystride,
                                              int n_rhs, int* __restrict__ status, double (*s_x)[64 * 6],
                                              int& s_bad, const double* lds_tile = nullptr,
-                                             const double* lds_rhs = nullptr, int lds_poses = 0) {
+                                             const double* lds_rhs = nullptr, int lds_poses = 0,
+                                             double* lds_out = nullptr, double* lds_rhs_out = nullptr) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
@@ -830,11 +834,26 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
     if (o_row >= 0) {
       double* dst = Sb + o_row;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) dst[c] = (6 * kb + c <= R) ? row[j][c] : 0.0;   // strict upper part of the diagonal blocks = 0
+      for (int c = 0; c < 6; ++c) {
+        const double v = (6 * kb + c <= R) ? row[j][c] : 0.0;   // strict upper part of the diagonal blocks = 0
+        if (PUBLISH) __hip_atomic_store(dst + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dst[c] = v;
+      }
+    }
+    if (PUBLISH && lds_out != nullptr && R < NB) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) lds_out[R * LDD + 6 * kb + c] = (o_row >= 0 && 6 * kb + c <= R) ? row[j][c] : 0.0;
     }
     if (is_rhs && kb < pb) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) yrow[6 * kb + c] = row[j][c];
+      for (int c = 0; c < 6; ++c) {
+        if (PUBLISH) __hip_atomic_store(yrow + 6 * kb + c, row[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else yrow[6 * kb + c] = row[j][c];
+      }
+    }
+    if (PUBLISH && lds_rhs_out != nullptr && R >= nb && R < nb + n_rhs) {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) lds_rhs_out[(R - nb) * NB + 6 * kb + c] = kb < pb ? row[j][c] : 0.0;
     }
   }
 }
@@ -848,6 +867,8 @@ struct BandSys {
   int* status;
   int* F;
   int n;
+  double* win_pub = nullptr;      // scratch of the persistent window kernel (window_doubles()); null: launches only
+  int* win_F = nullptr;
 };
 struct BandSet {
   BandSys s[2];
@@ -1724,6 +1745,457 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
   if (tid == 0 && __hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) status[0] = -1;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent window factorisation (factor_launches mode 3): the whole chain of panel steps in ONE launch.
+//
+// Why: a panel step issued as launches costs a TRSM launch (9 us: every workgroup stages L_D and rebuilds its inverse
+// blocks) + an update launch (15 us: tile (0,0)'s workgroup stages, multiplies, combines and THEN factors the next
+// panel) + two launch boundaries, all of it on the chain of n / 8 dependent steps; the update's ~400 other tiles take
+// as long only because they re-read and re-write the whole 7 MB window from memory every step.  Here
+//   * the sliding window lives in REGISTERS: tile (I, J) of 8 x 8 poses sits in the MFMA accumulators of one workgroup
+//     from its first update to its elimination (band_index.h, win_tile_of: D + 1 choose 2 slots, each hosting exactly
+//     one tile at every step; one workgroup per slot serves that slot of both systems of a two-sided solve);
+//   * one CRITICAL workgroup per system owns the chain: factor the diagonal tile (panel_factor), build the inverse
+//     blocks ONCE and publish them, solve the sub-diagonal tile, update the next diagonal tile, factor again -- it
+//     never waits for the bulk of the window, only for the two tiles of the next block row, which their owners hand
+//     over one step ahead;
+//   * everything that crosses workgroups (the factor L in its final place in Sband, the inverse blocks, the solved
+//     rows X, handed-over tiles, right-hand sides, the flags) is written and read ONLY with agent-scope 8-byte atomics
+//     (the protocol of chol_backsolve_kernel: store, drain, barrier, flag / poll, barrier, load), every wait is bounded
+//     (abort flag -> status -1, never a hang), and the grid is sized so that every workgroup is resident.
+// Flags of a system: F[0] = panels published by the critical workgroup, F[1] = abort, F[2 + I] = panels whose solved
+// rows of block row I are in memory, F[2 + NT + I] = tiles of block row I handed over (2 = both).
+struct WinSys {
+  double* Sb;
+  double* y;
+  int* status;
+  double* pub;      // [n_panels][WIN_PUB]: G(1,0), G(2,0), G(2,1), M_0, M_1, M_2 of every panel, 16 x 16 row-major each
+  int* F;
+  int n;
+};
+struct WinSet {
+  WinSys s[2];
+  int count;
+};
+constexpr int WIN_PUB = 6 * 256;
+constexpr int WIN_LDS_DOUBLES = 3 * UT * ULD + 3 * 16 * MLD + NB + 4 * BS_RHS_MAX * NB;
+constexpr int WIN_MIN_BAND = 2 * PB;      // at least two off-diagonal tile distances, else the critical workgroup owns everything
+
+__device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// tile (rows from pose pi0, columns from pose pj0) in its natural place in the band <-> LDS, row-major with stride LDD;
+// what the band does not store reads as zero
+__device__ __forceinline__ void win_load_tile(const double* Sb, int band, int n, int pi0, int pj0, double* T) {
+  // every load is issued before the first result is used (an atomic load behind a branch, or followed by its LDS store,
+  // would be one memory round trip per element: masked elements read Sb[0] instead and are zeroed afterwards)
+  constexpr int PER = UT * UT / 256;
+  double v[PER];
+  bool ok[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    const int Rr = e / UT, Cc = e - UT * Rr;
+    const long long o = bandidx::win_scalar(band, n, pi0, pj0, Rr, Cc);
+    ok[u] = o >= 0;
+    v[u] = ld_sc1(Sb + (ok[u] ? o : 0));
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int e = threadIdx.x + 256 * u;
+    const int Rr = e / UT, Cc = e - UT * Rr;
+    T[Rr * LDD + Cc] = ok[u] ? v[u] : 0.0;
+  }
+}
+__device__ __forceinline__ void win_store_tile(double* Sb, int band, int n, int pi0, int pj0, const double* T) {
+  for (int e = threadIdx.x; e < UT * UT; e += 256) {
+    const int Rr = e / UT, Cc = e - UT * Rr;
+    const long long o = bandidx::win_scalar(band, n, pi0, pj0, Rr, Cc);
+    if (o >= 0) st_sc1(Sb + o, T[Rr * LDD + Cc]);
+  }
+}
+// solved rows X of the 48-row tile at pose pose0 for the panel at pose k0: TRANSPOSED 6x6 blocks in memory <-> LDS row-major
+__device__ __forceinline__ void win_load_xtile(const double* Sb, int band, int k0, int pb, int i_last, int pose0, double* X) {
+  constexpr int ITEMS = UTP * PB * 6, PER = (ITEMS + 255) / 256;       // 384 items of 6 doubles: 2 per thread
+  double v[PER][6];
+  bool ok[PER];
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int item = threadIdx.x + 256 * u;
+    const long long o = item < ITEMS ? bandidx::solved_item(band, k0, pb, i_last, pose0, item) : -1;
+    ok[u] = o >= 0;
+    const double* src = Sb + (ok[u] ? o : 0);
+#pragma unroll
+    for (int r = 0; r < 6; ++r) v[u][r] = ld_sc1(src + r);
+  }
+#pragma unroll
+  for (int u = 0; u < PER; ++u) {
+    const int item = threadIdx.x + 256 * u;
+    if (item >= ITEMS) continue;
+    const int ii = item / (6 * PB), rem = item - 6 * PB * ii;
+    const int kk = rem / 6, c = rem - 6 * kk;
+    double* dst = X + (6 * ii) * ULD + 6 * kk + c;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) dst[r * ULD] = ok[u] ? v[u][r] : 0.0;
+  }
+}
+__device__ __forceinline__ void win_store_xtile(double* Sb, int band, int k0, int pb, int i_last, int pose0, const double* X) {
+  for (int item = threadIdx.x; item < UTP * PB * 6; item += 256) {
+    const int ii = item / (6 * PB), rem = item - 6 * PB * ii;
+    const int kk = rem / 6, c = rem - 6 * kk;
+    const long long o = bandidx::solved_item(band, k0, pb, i_last, pose0, item);
+    if (o < 0) continue;
+    const double* src = X + (6 * ii) * ULD + 6 * kk + c;
+#pragma unroll
+    for (int r = 0; r < 6; ++r) st_sc1(Sb + o + r, src[r * ULD]);
+  }
+}
+
+// acc (an MFMA accumulator set holding MINUS the tile) += Xi * Xjj^T; a diagonal tile keeps its lower MFMA tiles only
+__device__ __forceinline__ void win_mfma_update(double4_t (&acc)[UQ], const double* Xi, const double* Xjj, bool diag) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int arow = lane & 15, kq = lane >> 4;
+#pragma unroll
+  for (int q = 0; q < UQ; ++q) {
+    const int t = wave + 4 * q;
+    const int a = t / UMT, b = t - UMT * a;
+    if (t >= UMT * UMT || (diag && b > a)) continue;
+    const double* pa = Xi + (16 * a + arow) * ULD + kq;
+    const double* pbm = Xjj + (16 * b + arow) * ULD + kq;
+#pragma unroll
+    for (int s2 = 0; s2 < NB / 4; ++s2) acc[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s2], pbm[4 * s2], acc[q], 0, 0, 0);
+  }
+}
+
+// ---- the critical workgroup of one system ----
+__device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, double* smem, int& s_bad, int& s_go) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int arow = lane & 15, kq = lane >> 4;
+  const int n = B.n, NT = (n + PB - 1) / PB;
+  double* Xi = smem;                       // sub-diagonal tile A -> X; the ring of panel_factor while a panel is factored
+  double* Xn = Xi + UT * ULD;              // the next diagonal tile
+  double* sL = Xn + UT * ULD;              // the diagonal tile -> L_D -> (G blocks)
+  double* sM = sL + UT * ULD;
+  double* sInv = sM + 3 * 16 * MLD;
+  double* s_z = sInv + NB;                 // solved right-hand sides of the panel  [q][NB]
+  double* s_rhs = s_z + BS_RHS_MAX * NB;   // right-hand-side rows of the next panel  [q][NB]
+  int* F = B.F;
+  int* abort_flag = F + 1;
+  int* xflag = F + 2;
+  int* hand = F + 2 + NT;
+  const size_t ystride = 6 * (size_t)n;
+  win_load_tile(B.Sb, band, n, 0, 0, sL);
+  for (int e = tid; e < NB * n_rhs; e += 256) {
+    const int q = e / NB, c = e - NB * q;
+    s_rhs[e] = c < 6 * n ? ld_sc1(B.y + (size_t)q * ystride + c) : 0.0;
+  }
+  __syncthreads();
+  bool ok = true;
+#ifdef VUS_TIMING
+  unsigned long long wt[10];
+#define VUS_WT(k) wt[k] = __builtin_amdgcn_s_memtime()
+#else
+#define VUS_WT(k)
+#endif
+  for (int p = 0; p < NE; ++p) {
+    const int k0 = PB * p;
+    const int pb = min(PB, n - k0), nb = 6 * pb;
+    const int i_last = min(n - 1, k0 + pb - 1 + band);
+    VUS_WT(0);
+    panel_factor<true, true>(B.Sb, n, band, k0, B.y, ystride, n_rhs, B.status, reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad,
+                             sL, s_rhs, pb, sL, s_z);
+    __syncthreads();
+    VUS_WT(1);
+    if (tid < NB) sInv[tid] = tid < nb ? 1.0 / sL[tid * LDD + tid] : 1.0;
+    __syncthreads();
+    block_inverses(sL, sM, sInv);
+    VUS_WT(2);
+    {
+      double* pub = B.pub + (size_t)p * WIN_PUB;
+      for (int e = tid; e < WIN_PUB; e += 256) {
+        const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
+        const double v = blk < 3 ? sL[(16 * (blk == 0 ? 1 : 2) + r) * LDD + 16 * (blk == 2 ? 1 : 0) + c]
+                                 : sM[16 * MLD * (blk - 3) + MLD * r + c];
+        st_sc1(pub + e, v);
+      }
+    }
+    cb_drain();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(F, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // panel p is out
+    VUS_WT(3);
+    const int I = p + 1;
+    if (I >= NT) break;
+    // the next block row: its two right-most tiles carry every update before step p (handed over by their owners)
+    if (I >= 2) {
+      if (tid == 0) s_go = cb_wait(hand + I, 2, abort_flag);
+      __syncthreads();
+      if (!s_go) { ok = false; break; }
+    }
+    VUS_WT(4);
+    {
+      // both tiles and the right-hand-side rows in ONE batch of loads (20 per thread in flight, then the LDS stores)
+      constexpr int PER = UT * UT / 256;
+      double va[PER], vb[PER], vr[2];
+      bool oka[PER], okb[PER], okr[2];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int e = tid + 256 * u;
+        const int Rr = e / UT, Cc = e - UT * Rr;
+        const long long oa = bandidx::win_scalar(band, n, PB * I, k0, Rr, Cc);
+        const long long ob = bandidx::win_scalar(band, n, PB * I, PB * I, Rr, Cc);
+        oka[u] = oa >= 0;
+        okb[u] = ob >= 0;
+        va[u] = ld_sc1(B.Sb + (oka[u] ? oa : 0));
+        vb[u] = ld_sc1(B.Sb + (okb[u] ? ob : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {       // NB * n_rhs <= 384 right-hand-side elements
+        const int e = tid + 256 * u;
+        const int q = e / NB, c = e - NB * q;
+        okr[u] = e < NB * n_rhs && 6 * PB * I + c < 6 * n;
+        vr[u] = ld_sc1(B.y + (okr[u] ? (size_t)q * ystride + 6 * (size_t)PB * I + c : 0));
+      }
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int e = tid + 256 * u;
+        const int Rr = e / UT, Cc = e - UT * Rr;
+        Xi[Rr * LDD + Cc] = oka[u] ? va[u] : 0.0;
+        Xn[Rr * LDD + Cc] = okb[u] ? vb[u] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u;
+        if (e < NB * n_rhs) s_rhs[e] = okr[u] ? vr[u] : 0.0;
+      }
+    }
+    __syncthreads();
+    VUS_WT(5);
+    solve_rows(1, Xi, Xi, sL, sM);               // X of block row p+1
+    VUS_WT(6);
+    {
+      // next diagonal tile -= X X^T (lower MFMA tiles; every element of Xn belongs to one lane)
+#pragma unroll
+      for (int q = 0; q < UQ; ++q) {
+        const int t = wave + 4 * q;
+        const int a = t / UMT, b = t - UMT * a;
+        if (t >= UMT * UMT || b > a) continue;
+        double4_t acc;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = -Xn[(16 * a + kq + 4 * r) * LDD + 16 * b + arow];
+        const double* pa = Xi + (16 * a + arow) * ULD + kq;
+        const double* pbm = Xi + (16 * b + arow) * ULD + kq;
+#pragma unroll
+        for (int s2 = 0; s2 < NB / 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s2], pbm[4 * s2], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Xn[(16 * a + kq + 4 * r) * LDD + 16 * b + arow] = -acc[r];
+      }
+      // its right-hand sides -= X z
+      for (int e = tid; e < NB * n_rhs; e += 256) {
+        const int q = e / NB, r = e - NB * q;
+        double sum = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < NB; ++c) sum += Xi[r * ULD + c] * s_z[q * NB + c];
+        s_rhs[e] -= sum;
+      }
+    }
+    VUS_WT(7);
+    win_store_xtile(B.Sb, band, k0, pb, i_last, PB * I, Xi);
+    cb_drain();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(xflag + I, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    VUS_WT(8);
+#ifdef VUS_TIMING
+    if (tid == 0 && (p == 40 || p == 41) && NE > 60)
+      printf("WT p=%d factor %llu inv %llu publish %llu wait %llu load %llu solve %llu syrk %llu xstore %llu total %llu\n", p, wt[1] - wt[0],
+             wt[2] - wt[1], wt[3] - wt[2], wt[4] - wt[3], wt[5] - wt[4], wt[6] - wt[5], wt[7] - wt[6], wt[8] - wt[7], wt[8] - wt[0]);
+#endif
+    double* t_ = sL;
+    sL = Xn;
+    Xn = t_;
+  }
+  if (ok && NE < NT) {   // partial factorisation: the Schur complement's first diagonal tile and right-hand sides
+    win_store_tile(B.Sb, band, n, PB * NE, PB * NE, sL);
+    for (int e = tid; e < NB * n_rhs; e += 256) {
+      const int q = e / NB, c = e - NB * q;
+      if (6 * PB * NE + c < 6 * n) st_sc1(B.y + (size_t)q * ystride + 6 * (size_t)PB * NE + c, s_rhs[e]);
+    }
+  }
+}
+
+// ---- one window slot, for every system of the set ----
+__device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs, double* smem, int& s_go) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int arow = lane & 15, kq = lane >> 4;
+  const int n = S.s[0].n, NT = (n + PB - 1) / PB;
+  const int D = (band + PB - 1) / PB, M = D + 1;
+  double* Xi = smem;
+  double* Xj = Xi + UT * ULD;
+  double* sL = Xj + UT * ULD;
+  double* sM = sL + UT * ULD;
+  double* s_z = sM + 3 * 16 * MLD + NB;
+  double* s_yown = s_z + 2 * BS_RHS_MAX * NB;          // [2 systems][q][NB]: right-hand sides of a hosted diagonal tile
+  const size_t ystride = 6 * (size_t)n;
+  int hi, lo;
+  bandidx::win_slot_pair(slot, hi, lo);
+  double4_t acc[2][UQ];
+#pragma unroll
+  for (int y2 = 0; y2 < 2; ++y2)
+#pragma unroll
+    for (int q = 0; q < UQ; ++q) acc[y2][q] = double4_t{0.0, 0.0, 0.0, 0.0};
+  bool live = true;
+  for (int p = 0; p <= NE && live; ++p) {
+#pragma unroll
+    for (int sys = 0; sys < 2; ++sys) {
+      if (sys >= S.count || !live) continue;
+      const WinSys& B = S.s[sys];
+      int I, J;
+      bandidx::win_tile_of(hi, lo, M, p, I, J);
+      if (I >= NT) continue;                       // no such tile in this matrix
+      const int d = I - J;
+      if (d <= 1 && p > I - 2) continue;           // the critical workgroup's by now (rows 0 and 1: from the start)
+      const int birth = max(I - D, 0);
+      int* F = B.F;
+      int* abort_flag = F + 1;
+      int* xflag = F + 2;
+      int* hand = F + 2 + NT;
+      double* yown = s_yown + sys * BS_RHS_MAX * NB;
+      if (p == NE) {
+        // after the last step of a partial factorisation: what is still in registers goes back to its place
+        if (p > birth) {
+#pragma unroll
+          for (int q = 0; q < UQ; ++q) {
+            const int t = wave + 4 * q;
+            const int a = t / UMT, b = t - UMT * a;
+            if (t >= UMT * UMT) continue;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const long long o = bandidx::win_scalar(band, n, PB * I, PB * J, 16 * a + kq + 4 * r, 16 * b + arow);
+              if (o >= 0) st_sc1(B.Sb + o, -acc[sys][q][r]);
+            }
+          }
+          if (d == 0)
+            for (int e = tid; e < NB * n_rhs; e += 256) {
+              const int q = e / NB, c = e - NB * q;
+              if (6 * PB * I + c < 6 * n) st_sc1(B.y + (size_t)q * ystride + 6 * (size_t)PB * I + c, yown[e]);
+            }
+        }
+        continue;
+      }
+      const int k0 = PB * p;
+      const int pb = min(PB, n - k0);
+      const int i_last = min(n - 1, k0 + pb - 1 + band);
+      if (p == birth) {
+        // birth: the tile's entries of the assembled system (nobody has written them in this launch)
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          const int t = wave + 4 * q;
+          const int a = t / UMT, b = t - UMT * a;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long long o = t < UMT * UMT ? bandidx::win_scalar(band, n, PB * I, PB * J, 16 * a + kq + 4 * r, 16 * b + arow) : -1;
+            const double v = B.Sb[o >= 0 ? o : 0];       // unconditional load (masked: element 0), all twelve in flight
+            acc[sys][q][r] = o >= 0 ? -v : 0.0;
+          }
+        }
+        if (d == 0)
+          for (int e = tid; e < NB * n_rhs; e += 256) {
+            const int q = e / NB, c = e - NB * q;
+            yown[e] = 6 * PB * I + c < 6 * n ? B.y[(size_t)q * ystride + 6 * (size_t)PB * I + c] : 0.0;
+          }
+      }
+      if (J == p) {
+        // ---- elimination of the tile: X = A L_D^-T with the inverse blocks the critical workgroup published ----
+        if (tid == 0) s_go = cb_wait(F, p + 1, abort_flag);
+        __syncthreads();
+        if (!s_go) { live = false; continue; }
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          const int t = wave + 4 * q;
+          const int a = t / UMT, b = t - UMT * a;
+          if (t >= UMT * UMT) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) Xi[(16 * a + kq + 4 * r) * ULD + 16 * b + arow] = -acc[sys][q][r];
+        }
+        {
+          const double* pub = B.pub + (size_t)p * WIN_PUB;
+          double v[WIN_PUB / 256];
+#pragma unroll
+          for (int u = 0; u < WIN_PUB / 256; ++u) v[u] = ld_sc1(pub + tid + 256 * u);
+#pragma unroll
+          for (int u = 0; u < WIN_PUB / 256; ++u) {      // block u of the six, element tid
+            const int r = tid >> 4, c = tid & 15;
+            if (u < 3) sL[(16 * (u == 0 ? 1 : 2) + r) * LDD + 16 * (u == 2 ? 1 : 0) + c] = v[u];
+            else sM[16 * MLD * (u - 3) + MLD * r + c] = v[u];
+          }
+        }
+        __syncthreads();
+        solve_rows(1, Xi, Xi, sL, sM);
+        win_store_xtile(B.Sb, band, k0, pb, i_last, PB * I, Xi);
+        cb_drain();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_store(xflag + I, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        continue;
+      }
+      // ---- update with the solved rows of block rows I and J of panel p ----
+      if (tid == 0) s_go = cb_wait(xflag + I, p + 1, abort_flag) && (d == 0 || cb_wait(xflag + J, p + 1, abort_flag));
+      __syncthreads();
+      if (!s_go) { live = false; continue; }
+      win_load_xtile(B.Sb, band, k0, pb, i_last, PB * I, Xi);
+      if (d > 0) win_load_xtile(B.Sb, band, k0, pb, i_last, PB * J, Xj);
+      if (d == 0)
+        for (int e = tid; e < NB * n_rhs; e += 256) {
+          const int q = e / NB, c = e - NB * q;
+          s_z[e] = c < 6 * pb ? ld_sc1(B.y + (size_t)q * ystride + 6 * (size_t)k0 + c) : 0.0;
+        }
+      __syncthreads();
+      win_mfma_update(acc[sys], Xi, d == 0 ? Xi : Xj, d == 0);
+      if (d == 0)
+        for (int e = tid; e < NB * n_rhs; e += 256) {
+          const int q = e / NB, r = e - NB * q;
+          double sum = 0.0;
+#pragma unroll 8
+          for (int c = 0; c < NB; ++c) sum += Xi[r * ULD + c] * s_z[q * NB + c];
+          yown[e] -= sum;
+        }
+      if (d <= 1 && p == I - 2) {
+        // hand the tile (and a diagonal tile's right-hand sides) over to the critical workgroup
+#pragma unroll
+        for (int q = 0; q < UQ; ++q) {
+          const int t = wave + 4 * q;
+          const int a = t / UMT, b = t - UMT * a;
+          if (t >= UMT * UMT) continue;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const long long o = bandidx::win_scalar(band, n, PB * I, PB * J, 16 * a + kq + 4 * r, 16 * b + arow);
+            if (o >= 0) st_sc1(B.Sb + o, -acc[sys][q][r]);
+          }
+        }
+        __syncthreads();             // yown is complete
+        if (d == 0)
+          for (int e = tid; e < NB * n_rhs; e += 256) {
+            const int q = e / NB, c = e - NB * q;
+            if (6 * PB * I + c < 6 * n) st_sc1(B.y + (size_t)q * ystride + 6 * (size_t)PB * I + c, yown[e]);
+          }
+        cb_drain();
+        __syncthreads();
+        if (tid == 0) __hip_atomic_fetch_add(hand + I, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();               // Xi, Xj, s_z are free again
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void chol_window_kernel(WinSet S, int band, int NE, int n_rhs) {
+  extern __shared__ __attribute__((aligned(16))) double win_smem[];
+  __shared__ int s_bad, s_go;
+  const int bid = blockIdx.x;
+  if (bid < S.count) win_critical(S.s[bid], band, NE, n_rhs, win_smem, s_bad, s_go);
+  else win_bulk(S, bid - S.count, band, NE, n_rhs, win_smem, s_go);
+  if (threadIdx.x == 0)
+    for (int q = 0; q < S.count; ++q)
+      if (__hip_atomic_load(S.s[q].F + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) S.s[q].status[0] = -1;
+}
+
 __global__ void add_diag_kernel(double* __restrict__ Sband, int n_poses, int band, double value) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < 6 * n_poses) Sband[36 * (size_t)(t / 6) * (band + 1) + 7 * (t % 6)] += value;
@@ -1984,6 +2456,66 @@ int backsolve_max_wg() {
   return cap;
 }
 
+// Scratch of the persistent window kernel for one system of n poses of which n_panels panels are eliminated:
+// published inverse blocks (WIN_PUB doubles per panel) + flags, in doubles.
+size_t window_doubles(int n, int n_panels) {
+  const size_t NT = (size_t)(n + PB - 1) / PB;
+  return (size_t)n_panels * WIN_PUB + (2 + 2 * NT + 2) / 2 + 2;
+}
+
+// Workgroups of chol_window_kernel that are resident together (occupancy query x CUs, less a margin: the flags
+// protocol needs ALL of them running; a workgroup that is not resident after all ends in status -1, not in a hang).
+int window_capacity() {
+  static std::mutex mu;
+  static int cached[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+  std::lock_guard<std::mutex> lock(mu);
+  if (!cached[dev]) {
+    const int lds = WIN_LDS_DOUBLES * (int)sizeof(double);
+    int per_cu = 0;
+    const int n_cu = device_cu_count();
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(chol_window_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, chol_window_kernel, 256, lds) != hipSuccess)
+      per_cu = 0;
+    if (per_cu > 2) per_cu = 2;       // what __launch_bounds__(256, 2) and 76 KB of LDS were sized for
+    const int c = per_cu * n_cu - n_cu / 8;
+    cached[dev] = c > 0 ? c : -1;
+  }
+  return cached[dev] > 0 ? cached[dev] : 0;
+}
+
+// true if the persistent window kernel can run these systems (geometry, scratch, residency)
+bool window_applicable(const BandSet& S, int band, int n_elim) {
+  const int n = S.s[0].n;
+  if (band < WIN_MIN_BAND || n < 3 * PB || n_elim < PB) return false;
+  if (n_elim < n && n_elim % PB != 0) return false;
+  for (int q = 0; q < S.count; ++q)
+    if (!S.s[q].win_pub || !S.s[q].win_F || S.s[q].n != n) return false;
+  const int D = (band + PB - 1) / PB, M = D + 1;
+  return M * (M + 1) / 2 + S.count <= window_capacity();
+}
+
+int window_launch(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st) {
+  const int n = S.s[0].n, NT = (n + PB - 1) / PB;
+  const int NE = n_elim >= n ? NT : n_elim / PB;
+  const int D = (band + PB - 1) / PB, M = D + 1;
+  WinSet W;
+  W.count = S.count;
+  for (int q = 0; q < 2; ++q) {
+    const BandSys& b = S.s[q < S.count ? q : 0];
+    W.s[q] = WinSys{b.Sb, b.y, b.status, b.win_pub, b.win_F, b.n};
+  }
+  for (int q = 0; q < S.count; ++q)
+    VUS_CHECK_HIP(hipMemsetAsync(S.s[q].win_F, 0, sizeof(int) * (size_t)(2 + 2 * NT), st));
+  const int lds = WIN_LDS_DOUBLES * (int)sizeof(double);
+  VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_window_kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  chol_window_kernel<<<S.count + M * (M + 1) / 2, 256, lds, st>>>(W, band, NE, n_rhs);
+  VUS_CHECK_LAUNCH("ba_band_window");
+  return VUS_OK;
+}
+
 // Right-looking factorisation launches for the systems of S (identical geometry): panels 0 .. n_elim/PB - 1 are
 // eliminated (n_elim == S.s[0].n: the whole matrix; smaller, a multiple of PB: a PARTIAL factorisation that leaves the
 // Schur complement of the eliminated poses in the trailing window and the forward-substituted right-hand sides
@@ -1999,8 +2531,11 @@ int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream
   //     (band solve at configs[2]: mode 0 4.64 ms, mode 1 4.31 ms, mode 2 4.11 ms; the fused launch per half on two
   //     streams was measured too: 4.15 ms).
   int mode = S.count == 2 ? (st2 ? 2 : 1) : 0;
+  //  3  the persistent window kernel: ONE launch for the whole chain of panel steps of every system of S
+  //     (chol_window_kernel); the automatic choice wherever it applies (window_applicable).
   {
     const int m = g_knobs.band_mode.load(std::memory_order_relaxed);
+    if ((m < 0 || m == 3) && window_applicable(S, band, full ? n : n_elim)) return window_launch(S, band, full ? n : n_elim, n_rhs, st);
     if (m == 0 || m == 1 || (m == 2 && S.count == 2 && st2)) mode = m;
   }
   BandSet one[2];
@@ -2147,11 +2682,16 @@ int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st
   return VUS_OK;
 }
 
-int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, int* status, hipStream_t st) {
+int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, int* status, hipStream_t st,
+                    double* win_scratch = nullptr) {
   VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
   BandSet S;
   S.count = 1;
   S.s[0] = BandSys{Sband, y, status, nullptr, n_nodes};
+  if (win_scratch) {      // window_doubles(n_nodes, all panels)
+    S.s[0].win_pub = win_scratch;
+    S.s[0].win_F = reinterpret_cast<int*>(win_scratch + (size_t)((n_nodes + PB - 1) / PB) * WIN_PUB);
+  }
   S.s[1] = S.s[0];
   if (int rc = factor_launches(S, band, n_nodes, n_rhs, st)) return rc;
   return backsolve_launch(S, band, n_rhs, 0, st);
@@ -2169,7 +2709,7 @@ int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, 
 // Same arithmetic, the elimination order differs: results agree with the one-sided solve to round-off.
 struct SplitPlan {
   int n, band, n_rhs, m, nT, n_mid, bm;
-  size_t off_R, off_mid, off_yT, off_yR, off_yM, off_int, total;
+  size_t off_R, off_mid, off_yT, off_yR, off_yM, off_int, off_winT, off_winR, off_winM, total;
 };
 
 bool split_plan(int n, int band, int n_rhs, SplitPlan& p) {
@@ -2186,6 +2726,10 @@ bool split_plan(int n, int band, int n_rhs, SplitPlan& p) {
   p.off_yR = o;  o += 6 * (size_t)p.nT * n_rhs;
   p.off_yM = o;  o += 6 * (size_t)p.n_mid * n_rhs;
   p.off_int = o; o += 8;
+  // scratch of the persistent window kernel: the two halves (m / PB panels each) and the middle system
+  p.off_winT = o; o += window_doubles(p.nT, p.m / PB);
+  p.off_winR = o; o += window_doubles(p.nT, p.m / PB);
+  p.off_winM = o; o += window_doubles(p.n_mid, (p.n_mid + PB - 1) / PB);
   p.total = o;
   return true;
 }
@@ -2329,13 +2873,22 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
   S.count = 2;
   S.s[0] = BandSys{Sband, yT, status, nullptr, p.nT};
   S.s[1] = BandSys{Rb, yR, st_R, nullptr, p.nT};
+  {
+    double* w[2] = {work + p.off_winT, work + p.off_winR};
+    for (int q = 0; q < 2; ++q) {
+      S.s[q].win_pub = w[q];
+      S.s[q].win_F = reinterpret_cast<int*>(w[q] + (size_t)(p.m / PB) * WIN_PUB);
+    }
+  }
   // the halves are independent chains until the middle system: the pose-reversed one runs on a second stream
   const int mode_knob = g_knobs.band_mode.load(std::memory_order_relaxed);
-  SplitSection sec((mode_knob < 0 || mode_knob == 2) ? split_aux(st) : nullptr, st);
-  if (sec.a)
+  SplitSection sec((mode_knob < 0 || mode_knob >= 2) ? split_aux(st) : nullptr, st);
+  // (the persistent window kernel serves both halves in one launch on the caller's stream: nothing to fork for)
+  const bool halves_on_two_streams = sec.a && !((mode_knob < 0 || mode_knob == 3) && window_applicable(S, band, p.m));
+  if (halves_on_two_streams)
     if (int rc = sec.fork()) return rc;
-  if (int rc = factor_launches(S, band, p.m, n_rhs, st, sec.a ? sec.a->s2 : nullptr)) return rc;
-  if (sec.a)
+  if (int rc = factor_launches(S, band, p.m, n_rhs, st, halves_on_two_streams ? sec.a->s2 : nullptr)) return rc;
+  if (halves_on_two_streams)
     if (int rc = sec.join()) return rc;
   // the diagonal panels of both halves are inverted (for their back-substitution) beside the middle system's solve
   bool halves_inverted = false;
@@ -2345,7 +2898,7 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
   }
   const size_t nM = 36 * (size_t)p.n_mid * (p.bm + 1);
   split_mid_kernel<<<cdiv((long long)nM, 256), 256, 0, st>>>(Sband, y, p, Rb, yT, yR, Mid, yM);
-  if (int rc = band_solve_impl(Mid, p.n_mid, p.bm, yM, n_rhs, st_M, st)) return rc;
+  if (int rc = band_solve_impl(Mid, p.n_mid, p.bm, yM, n_rhs, st_M, st, work + p.off_winM)) return rc;
   const int n_spike = band < p.m ? band : p.m;
   split_spike_kernel<<<dim3(n_spike, 2, n_rhs), 64, 0, st>>>(Sband, Rb, p, yM, yT, yR);
   if (sec.open)
@@ -2360,7 +2913,7 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
 extern "C" int vus_ba_set_tuning(int knob, int value) {
   switch (knob) {
     case VUS_TUNE_BAND_MODE:
-      VUS_REQUIRE(value >= -1 && value <= 2, "band mode %d out of range [-1, 2]", value);
+      VUS_REQUIRE(value >= -1 && value <= 3, "band mode %d out of range [-1, 3]", value);
       g_knobs.band_mode = value;
       return VUS_OK;
     case VUS_TUNE_CB_MAX_WG:

@@ -79,6 +79,39 @@ VUS_HD long long tile_scalar(int band, int i_last, int pi0, int pj0, int Rr, int
   return ok ? blk(band, i, j) + 6 * rm + cm : -1;
 }
 
+// ---- chol_window: scalar (row Rr of the 48-row tile starting at pose pi0, column Cc of the tile starting at pose pj0)
+// of a tile ANYWHERE in the lower band (the tile may straddle the band's edge or the matrix's end): stored iff
+// j <= i <= min(n - 1, j + band), lower triangle on the diagonal.
+VUS_HD long long win_scalar(int band, int n, int pi0, int pj0, int Rr, int Cc) {
+  const int i = pi0 + Rr / 6, rm = Rr % 6;
+  const int j = pj0 + Cc / 6, cm = Cc % 6;
+  const bool ok = i < n && j <= i && i - j <= band && (j < i || cm <= rm);
+  return ok ? blk(band, i, j) + 6 * rm + cm : -1;
+}
+
+// ---- chol_window: which tile a window slot hosts at panel step p ----------------------------------------------------
+// Tiles are 8 x 8 poses; tile (I, J), J <= I <= J + D, is LIVE during the panel steps [I - D, J] (its first update to its
+// own elimination).  With M = D + 1, tile (I, J) is hosted by the slot of the unordered pair {I mod M, J mod M}: the two
+// orientations of a pair have complementary lifetimes (M - d and d steps of every M), so a slot hosts exactly one tile at
+// every step -- M (M + 1) / 2 slots for the whole sliding window, every one busy at every step.
+VUS_HD void win_slot_pair(int slot, int& hi, int& lo) {
+  hi = 0;
+  while ((hi + 1) * (hi + 2) / 2 <= slot) ++hi;
+  lo = slot - hi * (hi + 1) / 2;
+}
+VUS_HD void win_tile_of(int hi, int lo, int M, int p, int& I, int& J) {
+  const int d1 = hi - lo;
+  int r = (lo - p) % M;
+  if (r < 0) r += M;
+  if (r <= M - d1 - 1) {
+    J = p + r;
+    I = J + d1;
+  } else {
+    J = p + r + d1 - M;
+    I = J + (M - d1);
+  }
+}
+
 // ---- diag_invert: slot t of the lower block triangle of a panel (block row r6, distance sd, element e) ------------
 constexpr int DIAG_ELEMS = 36 * (PB * (PB + 1) / 2);
 VUS_HD void diag_slot(int t, int& r6, int& sd, int& e) {
