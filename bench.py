@@ -59,6 +59,9 @@ def parse():
     ap.add_argument("--cpu-frames", type=int, default=0, help="bounded cpu_baseline sample (0: sized from the core count)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-first-call", action="store_true", help="skip the fresh-process measurement of the first optimize()")
+    ap.add_argument("--no-object-graph", action="store_true", help="skip the per-object graph leg (~20 s of Python graph build)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the images -> trajectory leg")
     ap.add_argument("--ba-sharded-kf", type=int, default=10000, help="keyframes of the configs[4] leg run with N > 1 ranks")
     ap.add_argument("--pyramid", action="store_true", help="also measure the same stream through the 8-level x1.2 pyramid "
                     "(extra `pyramid8` object; off by default so that a profile of the default command sees one launch "
@@ -276,6 +279,12 @@ def main():
         else:
             dist.init_process_group(backend)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    first_call = None
+    if world == 1 and not a.no_ba and not a.no_first_call:
+        # batch.py:337 calls optimize() ONCE per process: measure that first call in a fresh child process, before this
+        # process has made any GPU call of its own (the two never share the GPU)
+        from visual_underwater_slam_amd import ba_bench as _bb
+        first_call = _bb.first_call_probe()
 
     from visual_underwater_slam_amd import dist as vdist
     from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
@@ -396,8 +405,13 @@ def main():
     torch.cuda.empty_cache()
     if not a.no_ba and world == 1:
         from visual_underwater_slam_amd import ba_bench
-        ba = ba_bench.run(device)
+        ba = ba_bench.run(device, with_object_graph=not a.no_object_graph)
         seq = ba.pop("_seq")
+        if first_call is not None and "dropin" in ba:
+            ba["dropin"]["first_call_s"] = first_call.get("first_call_s")
+            ba["dropin"]["first_call"] = first_call
+        if not a.no_end_to_end:
+            ba["end_to_end"] = ba_bench.run_end_to_end(device)
         # the reference's complete graph (stereo + IMU + DVL + priors) at its own plumbing size, configs[0] ...
         ba["full_graph_configs0"] = ba_bench.run_full_graph(device, 50, 500, 100)
         # ... and at 2000 keyframes: the sparse track of round 1 (about 120 factors per keyframe) and a dense one at the

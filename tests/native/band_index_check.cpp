@@ -145,8 +145,18 @@ void sweep_window(Sweep& S, int n_elim) {
           S.touch("win_scalar", off, 1, p, slot, Rr * 48 + Cc);
           S.expect("win_scalar", off, blk(band, PB * I + Rr / 6, PB * J + Cc / 6) + 6 * (Rr % 6) + Cc % 6, p, slot, Rr * 48 + Cc);
         }
+      for (int item = 0; item < 6 * UTP * PB; ++item) {       // the same tile by 48-byte row segments (16-byte buffer accesses)
+        const long long off = win_row(band, n, PB * I, PB * J, item >> 3, item & 7);
+        S.touch("win_row", off, 6, p, slot, item);
+        S.expect("win_row", off, blk(band, PB * I + (item >> 3) / 6, PB * J + (item & 7)) + 6 * ((item >> 3) % 6), p, slot, item);
+        if (off >= 0 && off % 2 != 0) S.fail("win_row: not 16-byte aligned", off, 6, p, slot, item);
+      }
       if (p < NE && I > p)
-        for (int item = 0; item < UTP * PB * 6; ++item) S.touch("solved_item/window", solved_item(band, k0, pb, i_last, PB * I, item), 6, p, slot, item);
+        for (int item = 0; item < UTP * PB * 6; ++item) {
+          const long long off = solved_item(band, k0, pb, i_last, PB * I, item);
+          S.touch("solved_item/window", off, 6, p, slot, item);
+          if (off >= 0 && off % 2 != 0) S.fail("solved_item: not 16-byte aligned", off, 6, p, slot, item);
+        }
     }
   }
 }

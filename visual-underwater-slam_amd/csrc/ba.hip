@@ -560,7 +560,12 @@ __global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure
         if (lane == 0) idx = atomicAdd(&s_next, 1);
         idx = __builtin_amdgcn_readfirstlane(idx);
         if (idx >= nb) break;
+#ifdef VUS_SR_DESC_K      // experiment: blocks in descending k (near-diagonal = largest first, and every wave of the row --
+                         // and the rows an XCD runs together -- inside one narrow slice of W at a time), no size sort
+        const int q = b1 - 1 - idx;
+#else
         const int q = b0 + (sorted ? (int)s_order[idx] : idx);
+#endif
         const int k = S.blk_k[q];
         int p0 = S.blk_ptr[q], p1 = S.blk_ptr[q + 1];
         if (!whole) {   // the pairs whose Y row lies in this chunk
@@ -912,6 +917,17 @@ __device__ unsigned long long g_tm[8];
 // Inverse blocks of the panel's 48x48 factor L_D held in sL (row stride LDD, zeros above the diagonal; sInv = 1 / diagonal,
 // 1 for the rows of a short last panel): M_b = (16x16 diagonal block b)^-1 -> sM, G_b = -M_b * L_D[row block b][columns <
 // 16 b] written over L_D's blocks (1,0), (2,0), (2,1) in sL.  Called by all 256 threads behind a barrier; ends in one.
+// Workgroup barrier that orders LDS traffic only: __syncthreads() also waits for every outstanding vector-memory
+// operation (s_waitcnt vmcnt(0)), i.e. for the write-through stores and the prefetching loads the persistent window
+// kernel keeps in flight on purpose.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+template <bool LDS_ONLY>
+__device__ __forceinline__ void wg_barrier() {
+  if (LDS_ONLY) lds_barrier();
+  else __syncthreads();
+}
+
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* __restrict__ sM,
                                                const double* __restrict__ sInv) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -935,7 +951,7 @@ __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* 
       for (int r = 0; r < 8; ++r) sM[16 * MLD * (h >> 1) + MLD * r + 8 + n] = 0.0;
     }
   }
-  __syncthreads();
+  wg_barrier<LDS_ONLY>();
   {
     const int b3 = tid >> 6, r = (tid >> 3) & 7, cq = tid & 7;   // threads < 192: element (r, cq) of quadrant C of block b3
     const bool act = tid < 192;
@@ -947,17 +963,17 @@ __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* 
       for (int k = 0; k < 8; ++k) t += Lc[k] * Mb[MLD * k + cq];
       Mb[MLD * (8 + r) + cq] = t;     // parked in the quadrant it will leave
     }
-    __syncthreads();
+    wg_barrier<LDS_ONLY>();
     if (act) {   // -B^-1 T
       double u = 0.0;
 #pragma unroll
       for (int k = 0; k < 8; ++k) u -= Mb[MLD * (8 + r) + 8 + k] * Mb[MLD * (8 + k) + cq];
       t = u;
     }
-    __syncthreads();
+    wg_barrier<LDS_ONLY>();
     if (act) Mb[MLD * (8 + r) + cq] = t;
   }
-  __syncthreads();
+  wg_barrier<LDS_ONLY>();
   VUS_TMARK(2);
   const int arow = lane & 15, kq = lane >> 4;
   if (wave < 3) {   // G tiles (b, kt) = (1,0), (2,0), (2,1):  -M_b * L_D[16b.., 16kt..], in place
@@ -977,7 +993,7 @@ __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* 
 #pragma unroll
     for (int r = 0; r < 4; ++r) sL[(16 * b + kq + 4 * r) * LDD + 16 * kt + arow] = -acc[r];
   }
-  __syncthreads();
+  wg_barrier<LDS_ONLY>();
   VUS_TMARK(3);
 }
 
@@ -985,6 +1001,7 @@ __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* 
 // substitution with the inverse blocks of block_inverses(),
 //   X_b = [X_0 .. X_b-1] * G_b^T + A_b * M_b^T   (4 b + 4 steps of v_mfma_f64_16x16x4_f64 per 16-row tile).
 // A 16-row tile belongs to one wave from start to end, so the three block steps need no workgroup barrier.  Ends in one.
+template <bool LDS_ONLY = false>
 __device__ __forceinline__ void solve_rows(int n_tiles, double* __restrict__ Xa, double* __restrict__ Xb,
                                            const double* __restrict__ sL, const double* __restrict__ sM) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1027,7 +1044,7 @@ __device__ __forceinline__ void solve_rows(int n_tiles, double* __restrict__ Xa,
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     }
   }
-  __syncthreads();
+  wg_barrier<LDS_ONLY>();
   VUS_TMARK(4);
 }
 
@@ -1784,70 +1801,101 @@ constexpr int WIN_MIN_BAND = 2 * PB;      // at least two off-diagonal tile dist
 __device__ __forceinline__ double ld_sc1(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void st_sc1(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// tile (rows from pose pi0, columns from pose pj0) in its natural place in the band <-> LDS, row-major with stride LDD;
-// what the band does not store reads as zero
-__device__ __forceinline__ void win_load_tile(const double* Sb, int band, int n, int pi0, int pj0, double* T) {
-  // every load is issued before the first result is used (an atomic load behind a branch, or followed by its LDS store,
-  // would be one memory round trip per element: masked elements read Sb[0] instead and are zeroed afterwards)
-  constexpr int PER = UT * UT / 256;
-  double v[PER];
-  bool ok[PER];
+// 16-byte agent-scope (sc1) accesses through a buffer descriptor of the whole band: a third of the memory transactions
+// of 8-byte atomics for the 48-byte row segments everything here moves, and a masked lane simply addresses past the
+// buffer's end (the load returns zeros, the store is dropped: hardware range check, no branch).
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+constexpr unsigned WIN_OOB = 0xFFFFFFF0u;
+__device__ __forceinline__ rsrc_t win_rsrc(const void* p, long long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(unsigned)bytes, 0x00020000);
+}
+__device__ __forceinline__ unsigned win_off(long long off_doubles) { return off_doubles >= 0 ? (unsigned)(8 * off_doubles) : WIN_OOB; }
+__device__ __forceinline__ d2a_t ld16_sc1(rsrc_t r, unsigned byte_off) {
+  const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 16);
+  return __builtin_bit_cast(d2a_t, v);
+}
+__device__ __forceinline__ void st16_sc1(rsrc_t r, unsigned byte_off, d2a_t v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)byte_off, 0, 16);
+}
+
+// A 48 x 48 tile as 384 row segments of 6 doubles (2 per thread, the second for half the threads): registers of a fetch
+// that is issued at one point of the program and committed to LDS at another.
+constexpr int WIN_ITEMS = UT * PB;                  // 384
+struct WinFetch {
+  d2a_t v[2][3];
+};
+// natural layout: item = (scalar row Rr = item >> 3, block column kk = item & 7)
+__device__ __forceinline__ void win_fetch_tile(rsrc_t rs, int band, int n, int pi0, int pj0, WinFetch& f) {
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int e = threadIdx.x + 256 * u;
-    const int Rr = e / UT, Cc = e - UT * Rr;
-    const long long o = bandidx::win_scalar(band, n, pi0, pj0, Rr, Cc);
-    ok[u] = o >= 0;
-    v[u] = ld_sc1(Sb + (ok[u] ? o : 0));
-  }
+  for (int u = 0; u < 2; ++u) {
+    const int item = threadIdx.x + 256 * u;
+    const unsigned o = item < WIN_ITEMS ? win_off(bandidx::win_row(band, n, pi0, pj0, item >> 3, item & 7)) : WIN_OOB;
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
-    const int e = threadIdx.x + 256 * u;
-    const int Rr = e / UT, Cc = e - UT * Rr;
-    T[Rr * LDD + Cc] = ok[u] ? v[u] : 0.0;
+    for (int h = 0; h < 3; ++h) f.v[u][h] = ld16_sc1(rs, o == WIN_OOB ? WIN_OOB : o + 16 * h);
   }
 }
-__device__ __forceinline__ void win_store_tile(double* Sb, int band, int n, int pi0, int pj0, const double* T) {
-  for (int e = threadIdx.x; e < UT * UT; e += 256) {
-    const int Rr = e / UT, Cc = e - UT * Rr;
-    const long long o = bandidx::win_scalar(band, n, pi0, pj0, Rr, Cc);
-    if (o >= 0) st_sc1(Sb + o, T[Rr * LDD + Cc]);
+__device__ __forceinline__ void win_commit_tile(const WinFetch& f, double* T) {     // row-major, stride LDD
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int item = threadIdx.x + 256 * u;
+    if (item >= WIN_ITEMS) continue;
+    double* dst = T + (item >> 3) * LDD + 6 * (item & 7);
+#pragma unroll
+    for (int h = 0; h < 3; ++h) {
+      dst[2 * h] = f.v[u][h].x;
+      dst[2 * h + 1] = f.v[u][h].y;
+    }
   }
 }
-// solved rows X of the 48-row tile at pose pose0 for the panel at pose k0: TRANSPOSED 6x6 blocks in memory <-> LDS row-major
-__device__ __forceinline__ void win_load_xtile(const double* Sb, int band, int k0, int pb, int i_last, int pose0, double* X) {
-  constexpr int ITEMS = UTP * PB * 6, PER = (ITEMS + 255) / 256;       // 384 items of 6 doubles: 2 per thread
-  double v[PER][6];
-  bool ok[PER];
+__device__ __forceinline__ void win_store_tile(rsrc_t rs, int band, int n, int pi0, int pj0, const double* T) {
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
+  for (int u = 0; u < 2; ++u) {
     const int item = threadIdx.x + 256 * u;
-    const long long o = item < ITEMS ? bandidx::solved_item(band, k0, pb, i_last, pose0, item) : -1;
-    ok[u] = o >= 0;
-    const double* src = Sb + (ok[u] ? o : 0);
+    if (item >= WIN_ITEMS) continue;
+    const unsigned o = win_off(bandidx::win_row(band, n, pi0, pj0, item >> 3, item & 7));
+    const double* src = T + (item >> 3) * LDD + 6 * (item & 7);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) v[u][r] = ld_sc1(src + r);
+    for (int h = 0; h < 3; ++h) st16_sc1(rs, o == WIN_OOB ? WIN_OOB : o + 16 * h, d2a_t{src[2 * h], src[2 * h + 1]});
   }
+}
+// solved rows X (TRANSPOSED 6x6 blocks in memory): item = (pose ii, panel pose kk, column c): rows 6 ii .. 6 ii + 5 of
+// column 6 kk + c of the LDS tile (row-major, stride ULD)
+__device__ __forceinline__ void win_fetch_xtile(rsrc_t rs, int band, int k0, int pb, int i_last, int pose0, WinFetch& f) {
 #pragma unroll
-  for (int u = 0; u < PER; ++u) {
+  for (int u = 0; u < 2; ++u) {
     const int item = threadIdx.x + 256 * u;
-    if (item >= ITEMS) continue;
+    const unsigned o = item < WIN_ITEMS ? win_off(bandidx::solved_item(band, k0, pb, i_last, pose0, item)) : WIN_OOB;
+#pragma unroll
+    for (int h = 0; h < 3; ++h) f.v[u][h] = ld16_sc1(rs, o == WIN_OOB ? WIN_OOB : o + 16 * h);
+  }
+}
+__device__ __forceinline__ void win_commit_xtile(const WinFetch& f, double* X) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int item = threadIdx.x + 256 * u;
+    if (item >= WIN_ITEMS) continue;
     const int ii = item / (6 * PB), rem = item - 6 * PB * ii;
     const int kk = rem / 6, c = rem - 6 * kk;
     double* dst = X + (6 * ii) * ULD + 6 * kk + c;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) dst[r * ULD] = ok[u] ? v[u][r] : 0.0;
+    for (int h = 0; h < 3; ++h) {
+      dst[(2 * h) * ULD] = f.v[u][h].x;
+      dst[(2 * h + 1) * ULD] = f.v[u][h].y;
+    }
   }
 }
-__device__ __forceinline__ void win_store_xtile(double* Sb, int band, int k0, int pb, int i_last, int pose0, const double* X) {
-  for (int item = threadIdx.x; item < UTP * PB * 6; item += 256) {
+__device__ __forceinline__ void win_store_xtile(rsrc_t rs, int band, int k0, int pb, int i_last, int pose0, const double* X) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int item = threadIdx.x + 256 * u;
+    if (item >= WIN_ITEMS) continue;
+    const unsigned o = win_off(bandidx::solved_item(band, k0, pb, i_last, pose0, item));
     const int ii = item / (6 * PB), rem = item - 6 * PB * ii;
     const int kk = rem / 6, c = rem - 6 * kk;
-    const long long o = bandidx::solved_item(band, k0, pb, i_last, pose0, item);
-    if (o < 0) continue;
     const double* src = X + (6 * ii) * ULD + 6 * kk + c;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) st_sc1(Sb + o + r, src[r * ULD]);
+    for (int h = 0; h < 3; ++h) st16_sc1(rs, o == WIN_OOB ? WIN_OOB : o + 16 * h, d2a_t{src[(2 * h) * ULD], src[(2 * h + 1) * ULD]});
   }
 }
 
@@ -1884,7 +1932,13 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
   int* xflag = F + 2;
   int* hand = F + 2 + NT;
   const size_t ystride = 6 * (size_t)n;
-  win_load_tile(B.Sb, band, n, 0, 0, sL);
+  const rsrc_t rsS = win_rsrc(B.Sb, 8 * bandidx::band_doubles(n, band));
+  const rsrc_t rsP = win_rsrc(B.pub, 8ll * WIN_PUB * NE);
+  {
+    WinFetch f0;
+    win_fetch_tile(rsS, band, n, 0, 0, f0);
+    win_commit_tile(f0, sL);
+  }
   for (int e = tid; e < NB * n_rhs; e += 256) {
     const int q = e / NB, c = e - NB * q;
     s_rhs[e] = c < 6 * n ? ld_sc1(B.y + (size_t)q * ystride + c) : 0.0;
@@ -1904,50 +1958,24 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     VUS_WT(0);
     panel_factor<true, true>(B.Sb, n, band, k0, B.y, ystride, n_rhs, B.status, reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad,
                              sL, s_rhs, pb, sL, s_z);
-    __syncthreads();
+    lds_barrier();                 // the factor's stores to memory stay in flight
     VUS_WT(1);
-    if (tid < NB) sInv[tid] = tid < nb ? 1.0 / sL[tid * LDD + tid] : 1.0;
-    __syncthreads();
-    block_inverses(sL, sM, sInv);
-    VUS_WT(2);
-    {
-      double* pub = B.pub + (size_t)p * WIN_PUB;
-      for (int e = tid; e < WIN_PUB; e += 256) {
-        const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
-        const double v = blk < 3 ? sL[(16 * (blk == 0 ? 1 : 2) + r) * LDD + 16 * (blk == 2 ? 1 : 0) + c]
-                                 : sM[16 * MLD * (blk - 3) + MLD * r + c];
-        st_sc1(pub + e, v);
-      }
-    }
-    cb_drain();
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(F, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // panel p is out
-    VUS_WT(3);
     const int I = p + 1;
-    if (I >= NT) break;
-    // the next block row: its two right-most tiles carry every update before step p (handed over by their owners)
-    if (I >= 2) {
-      if (tid == 0) s_go = cb_wait(hand + I, 2, abort_flag);
-      __syncthreads();
-      if (!s_go) { ok = false; break; }
-    }
-    VUS_WT(4);
-    {
-      // both tiles and the right-hand-side rows in ONE batch of loads (20 per thread in flight, then the LDS stores)
-      constexpr int PER = UT * UT / 256;
-      double va[PER], vb[PER], vr[2];
-      bool oka[PER], okb[PER], okr[2];
-#pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int e = tid + 256 * u;
-        const int Rr = e / UT, Cc = e - UT * Rr;
-        const long long oa = bandidx::win_scalar(band, n, PB * I, k0, Rr, Cc);
-        const long long ob = bandidx::win_scalar(band, n, PB * I, PB * I, Rr, Cc);
-        oka[u] = oa >= 0;
-        okb[u] = ob >= 0;
-        va[u] = ld_sc1(B.Sb + (oka[u] ? oa : 0));
-        vb[u] = ld_sc1(B.Sb + (okb[u] ? ob : 0));
+    const bool more = I < NT;
+    // The next block row's two right-most tiles carry every update before step p; their owners handed them over while
+    // this panel was being factored.  Their loads are issued NOW and land while the inverse blocks are computed.
+    WinFetch fa, fb;
+    double vr[2];
+    bool okr[2];
+    if (more) {
+      if (I >= 2) {
+        if (tid == 0) s_go = cb_wait(hand + I, 2, abort_flag);
+        lds_barrier();
+        if (!s_go) { ok = false; break; }
       }
+      VUS_WT(4);
+      win_fetch_tile(rsS, band, n, PB * I, k0, fa);
+      win_fetch_tile(rsS, band, n, PB * I, PB * I, fb);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {       // NB * n_rhs <= 384 right-hand-side elements
         const int e = tid + 256 * u;
@@ -1955,30 +1983,48 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
         okr[u] = e < NB * n_rhs && 6 * PB * I + c < 6 * n;
         vr[u] = ld_sc1(B.y + (okr[u] ? (size_t)q * ystride + 6 * (size_t)PB * I + c : 0));
       }
+    }
+    if (tid < NB) sInv[tid] = tid < nb ? 1.0 / sL[tid * LDD + tid] : 1.0;
+    lds_barrier();
+    block_inverses<true>(sL, sM, sInv);
+    VUS_WT(2);
+    {
+      // the six 16 x 16 blocks G(1,0), G(2,0), G(2,1), M_0, M_1, M_2, row-major: 768 pairs of doubles, 3 per thread
 #pragma unroll
-      for (int u = 0; u < PER; ++u) {
-        const int e = tid + 256 * u;
-        const int Rr = e / UT, Cc = e - UT * Rr;
-        Xi[Rr * LDD + Cc] = oka[u] ? va[u] : 0.0;
-        Xn[Rr * LDD + Cc] = okb[u] ? vb[u] : 0.0;
-      }
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int e = tid + 256 * u;
-        if (e < NB * n_rhs) s_rhs[e] = okr[u] ? vr[u] : 0.0;
+      for (int u = 0; u < WIN_PUB / 512; ++u) {
+        const int e2 = tid + 256 * u;                  // pair index: block e2 >> 7, row (e2 >> 3) & 15, columns 2 (e2 & 7)
+        const int blk = e2 >> 7, r = (e2 >> 3) & 15, c = 2 * (e2 & 7);
+        const double* src = blk < 3 ? sL + (16 * (blk == 0 ? 1 : 2) + r) * LDD + 16 * (blk == 2 ? 1 : 0) + c
+                                    : sM + 16 * MLD * (blk - 3) + MLD * r + c;
+        st16_sc1(rsP, (unsigned)(8 * ((size_t)p * WIN_PUB) + 16 * e2), d2a_t{src[0], src[1]});
       }
     }
-    __syncthreads();
-    VUS_WT(5);
-    solve_rows(1, Xi, Xi, sL, sM);               // X of block row p+1
-    VUS_WT(6);
-    {
-      // next diagonal tile -= X X^T (lower MFMA tiles; every element of Xn belongs to one lane)
+    cb_drain();                    // the factor, the solved right-hand sides, the inverse blocks are in memory (and the
+    __syncthreads();               // tile loads above have landed)
+    if (tid == 0) __hip_atomic_store(F, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // panel p is out
+    VUS_WT(3);
+    if (!more) break;
+    win_commit_tile(fa, Xi);
+    win_commit_tile(fb, Xn);
 #pragma unroll
-      for (int q = 0; q < UQ; ++q) {
-        const int t = wave + 4 * q;
+    for (int u = 0; u < 2; ++u) {
+      const int e = tid + 256 * u;
+      if (e < NB * n_rhs) s_rhs[e] = okr[u] ? vr[u] : 0.0;
+    }
+    lds_barrier();
+    VUS_WT(5);
+    solve_rows<true>(1, Xi, Xi, sL, sM);         // X of block row p+1
+    VUS_WT(6);
+    win_store_xtile(rsS, band, k0, pb, i_last, PB * I, Xi);      // on its way to memory while the update below runs
+    {
+      // next diagonal tile -= X X^T: its six lower MFMA tiles, at most two per wave; every element of Xn belongs to
+      // one lane
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        // tile index t = 3 a + b: wave 0 -> (0,0), (2,1); wave 1 -> (1,0), (2,2); wave 2 -> (1,1); wave 3 -> (2,0)
+        const int t = q == 0 ? (wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 4 : 6) : (wave == 0 ? 7 : wave == 1 ? 8 : -1);
+        if (t < 0) continue;
         const int a = t / UMT, b = t - UMT * a;
-        if (t >= UMT * UMT || b > a) continue;
         double4_t acc;
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = -Xn[(16 * a + kq + 4 * r) * LDD + 16 * b + arow];
@@ -1989,32 +2035,32 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
 #pragma unroll
         for (int r = 0; r < 4; ++r) Xn[(16 * a + kq + 4 * r) * LDD + 16 * b + arow] = -acc[r];
       }
-      // its right-hand sides -= X z
-      for (int e = tid; e < NB * n_rhs; e += 256) {
-        const int q = e / NB, r = e - NB * q;
-        double sum = 0.0;
+      // its right-hand sides -= X z (the waves with one MFMA tile take them)
+      if (wave >= 2)
+        for (int e = tid - 128; e < NB * n_rhs; e += 128) {
+          const int q = e / NB, r = e - NB * q;
+          double sum = 0.0;
 #pragma unroll 8
-        for (int c = 0; c < NB; ++c) sum += Xi[r * ULD + c] * s_z[q * NB + c];
-        s_rhs[e] -= sum;
-      }
+          for (int c = 0; c < NB; ++c) sum += Xi[r * ULD + c] * s_z[q * NB + c];
+          s_rhs[e] -= sum;
+        }
     }
     VUS_WT(7);
-    win_store_xtile(B.Sb, band, k0, pb, i_last, PB * I, Xi);
     cb_drain();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(xflag + I, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     VUS_WT(8);
 #ifdef VUS_TIMING
     if (tid == 0 && (p == 40 || p == 41) && NE > 60)
-      printf("WT p=%d factor %llu inv %llu publish %llu wait %llu load %llu solve %llu syrk %llu xstore %llu total %llu\n", p, wt[1] - wt[0],
-             wt[2] - wt[1], wt[3] - wt[2], wt[4] - wt[3], wt[5] - wt[4], wt[6] - wt[5], wt[7] - wt[6], wt[8] - wt[7], wt[8] - wt[0]);
+      printf("WT p=%d factor %llu wait %llu inv %llu publish %llu commit %llu solve %llu syrk %llu xflag %llu total %llu\n", p, wt[1] - wt[0],
+             wt[4] - wt[1], wt[2] - wt[4], wt[3] - wt[2], wt[5] - wt[3], wt[6] - wt[5], wt[7] - wt[6], wt[8] - wt[7], wt[8] - wt[0]);
 #endif
     double* t_ = sL;
     sL = Xn;
     Xn = t_;
   }
   if (ok && NE < NT) {   // partial factorisation: the Schur complement's first diagonal tile and right-hand sides
-    win_store_tile(B.Sb, band, n, PB * NE, PB * NE, sL);
+    win_store_tile(rsS, band, n, PB * NE, PB * NE, sL);
     for (int e = tid; e < NB * n_rhs; e += 256) {
       const int q = e / NB, c = e - NB * q;
       if (6 * PB * NE + c < 6 * n) st_sc1(B.y + (size_t)q * ystride + 6 * (size_t)PB * NE + c, s_rhs[e]);
@@ -2059,20 +2105,22 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
       int* xflag = F + 2;
       int* hand = F + 2 + NT;
       double* yown = s_yown + sys * BS_RHS_MAX * NB;
+      const rsrc_t rsS = win_rsrc(B.Sb, 8 * bandidx::band_doubles(n, band));
+      const rsrc_t rsP = win_rsrc(B.pub, 8ll * WIN_PUB * NE);
       if (p == NE) {
         // after the last step of a partial factorisation: what is still in registers goes back to its place
         if (p > birth) {
+          __syncthreads();
 #pragma unroll
           for (int q = 0; q < UQ; ++q) {
             const int t = wave + 4 * q;
             const int a = t / UMT, b = t - UMT * a;
             if (t >= UMT * UMT) continue;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              const long long o = bandidx::win_scalar(band, n, PB * I, PB * J, 16 * a + kq + 4 * r, 16 * b + arow);
-              if (o >= 0) st_sc1(B.Sb + o, -acc[sys][q][r]);
-            }
+            for (int r = 0; r < 4; ++r) Xi[(16 * a + kq + 4 * r) * LDD + 16 * b + arow] = -acc[sys][q][r];
           }
+          __syncthreads();
+          win_store_tile(rsS, band, n, PB * I, PB * J, Xi);
           if (d == 0)
             for (int e = tid; e < NB * n_rhs; e += 256) {
               const int q = e / NB, c = e - NB * q;
@@ -2117,20 +2165,22 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
           for (int r = 0; r < 4; ++r) Xi[(16 * a + kq + 4 * r) * ULD + 16 * b + arow] = -acc[sys][q][r];
         }
         {
-          const double* pub = B.pub + (size_t)p * WIN_PUB;
-          double v[WIN_PUB / 256];
+          d2a_t v[WIN_PUB / 512];
 #pragma unroll
-          for (int u = 0; u < WIN_PUB / 256; ++u) v[u] = ld_sc1(pub + tid + 256 * u);
+          for (int u = 0; u < WIN_PUB / 512; ++u) v[u] = ld16_sc1(rsP, (unsigned)(8 * ((size_t)p * WIN_PUB) + 16 * (tid + 256 * u)));
 #pragma unroll
-          for (int u = 0; u < WIN_PUB / 256; ++u) {      // block u of the six, element tid
-            const int r = tid >> 4, c = tid & 15;
-            if (u < 3) sL[(16 * (u == 0 ? 1 : 2) + r) * LDD + 16 * (u == 2 ? 1 : 0) + c] = v[u];
-            else sM[16 * MLD * (u - 3) + MLD * r + c] = v[u];
+          for (int u = 0; u < WIN_PUB / 512; ++u) {
+            const int e2 = tid + 256 * u;
+            const int blk = e2 >> 7, r = (e2 >> 3) & 15, c = 2 * (e2 & 7);
+            double* dst = blk < 3 ? sL + (16 * (blk == 0 ? 1 : 2) + r) * LDD + 16 * (blk == 2 ? 1 : 0) + c
+                                  : sM + 16 * MLD * (blk - 3) + MLD * r + c;
+            dst[0] = v[u].x;
+            dst[1] = v[u].y;
           }
         }
         __syncthreads();
         solve_rows(1, Xi, Xi, sL, sM);
-        win_store_xtile(B.Sb, band, k0, pb, i_last, PB * I, Xi);
+        win_store_xtile(rsS, band, k0, pb, i_last, PB * I, Xi);
         cb_drain();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(xflag + I, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2140,8 +2190,13 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
       if (tid == 0) s_go = cb_wait(xflag + I, p + 1, abort_flag) && (d == 0 || cb_wait(xflag + J, p + 1, abort_flag));
       __syncthreads();
       if (!s_go) { live = false; continue; }
-      win_load_xtile(B.Sb, band, k0, pb, i_last, PB * I, Xi);
-      if (d > 0) win_load_xtile(B.Sb, band, k0, pb, i_last, PB * J, Xj);
+      {
+        WinFetch fi, fj;
+        win_fetch_xtile(rsS, band, k0, pb, i_last, PB * I, fi);
+        if (d > 0) win_fetch_xtile(rsS, band, k0, pb, i_last, PB * J, fj);
+        win_commit_xtile(fi, Xi);
+        if (d > 0) win_commit_xtile(fj, Xj);
+      }
       if (d == 0)
         for (int e = tid; e < NB * n_rhs; e += 256) {
           const int q = e / NB, c = e - NB * q;
@@ -2159,17 +2214,17 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
         }
       if (d <= 1 && p == I - 2) {
         // hand the tile (and a diagonal tile's right-hand sides) over to the critical workgroup
+        __syncthreads();             // every wave has read its X fragments: Xi is free
 #pragma unroll
         for (int q = 0; q < UQ; ++q) {
           const int t = wave + 4 * q;
           const int a = t / UMT, b = t - UMT * a;
           if (t >= UMT * UMT) continue;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const long long o = bandidx::win_scalar(band, n, PB * I, PB * J, 16 * a + kq + 4 * r, 16 * b + arow);
-            if (o >= 0) st_sc1(B.Sb + o, -acc[sys][q][r]);
-          }
+          for (int r = 0; r < 4; ++r) Xi[(16 * a + kq + 4 * r) * LDD + 16 * b + arow] = -acc[sys][q][r];
         }
+        __syncthreads();
+        win_store_tile(rsS, band, n, PB * I, PB * J, Xi);
         __syncthreads();             // yown is complete
         if (d == 0)
           for (int e = tid; e < NB * n_rhs; e += 256) {
@@ -2460,7 +2515,7 @@ int backsolve_max_wg() {
 // published inverse blocks (WIN_PUB doubles per panel) + flags, in doubles.
 size_t window_doubles(int n, int n_panels) {
   const size_t NT = (size_t)(n + PB - 1) / PB;
-  return (size_t)n_panels * WIN_PUB + (2 + 2 * NT + 2) / 2 + 2;
+  return ((size_t)n_panels * WIN_PUB + (2 + 2 * NT + 2) / 2 + 3) & ~(size_t)1;     // even: what follows stays 16-byte aligned
 }
 
 // Workgroups of chol_window_kernel that are resident together (occupancy query x CUs, less a margin: the flags
@@ -2489,6 +2544,7 @@ int window_capacity() {
 bool window_applicable(const BandSet& S, int band, int n_elim) {
   const int n = S.s[0].n;
   if (band < WIN_MIN_BAND || n < 3 * PB || n_elim < PB) return false;
+  if (8 * bandidx::band_doubles(n, band) >= (1ll << 32)) return false;      // the kernel addresses the band through 32-bit buffer offsets
   if (n_elim < n && n_elim % PB != 0) return false;
   for (int q = 0; q < S.count; ++q)
     if (!S.s[q].win_pub || !S.s[q].win_F || S.s[q].n != n) return false;

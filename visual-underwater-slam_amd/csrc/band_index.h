@@ -89,6 +89,16 @@ VUS_HD long long win_scalar(int band, int n, int pi0, int pj0, int Rr, int Cc) {
   return ok ? blk(band, i, j) + 6 * rm + cm : -1;
 }
 
+// the same tile by ROW SEGMENTS: item = (scalar row Rr, block column kk) -> the 6 contiguous doubles of that row inside
+// block (pi0 + Rr / 6, pj0 + kk), or -1 if the band does not store the block.  (On a diagonal block the segment includes
+// the block's upper triangle, which nobody reads: the factor kernels use lower triangles only.)
+VUS_HD long long win_row(int band, int n, int pi0, int pj0, int Rr, int kk) {
+  const int i = pi0 + Rr / 6, rm = Rr % 6;
+  const int j = pj0 + kk;
+  const bool ok = i < n && j <= i && i - j <= band;
+  return ok ? blk(band, i, j) + 6 * rm : -1;
+}
+
 // ---- chol_window: which tile a window slot hosts at panel step p ----------------------------------------------------
 // Tiles are 8 x 8 poses; tile (I, J), J <= I <= J + D, is LIVE during the panel steps [I - D, J] (its first update to its
 // own elimination).  With M = D + 1, tile (I, J) is hosted by the slot of the unordered pair {I mod M, J mod M}: the two
