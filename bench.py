@@ -280,7 +280,12 @@ def main():
             dist.init_process_group(backend)
     assert a.gpus == world, f"--gpus {a.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     first_call = None
-    if world == 1 and not a.no_ba and not a.no_first_call:
+    under_profiler = "rocprofiler" in os.environ.get("LD_PRELOAD", "") or any(k.startswith("ROCP") for k in os.environ)
+    if world == 1 and not a.no_ba and not a.no_first_call and under_profiler:
+        # rocprofv3's preloaded tool may already have initialised the GPU in this process: starting a child from it is
+        # what the GPU pool forbids.  The figure comes from the plain run (profiles/bench_rNN.json).
+        first_call = {"skipped": "running under rocprofv3: no child process is started from a profiled process"}
+    elif world == 1 and not a.no_ba and not a.no_first_call:
         # batch.py:337 calls optimize() ONCE per process: measure that first call in a fresh child process, before this
         # process has made any GPU call of its own (the two never share the GPU)
         from visual_underwater_slam_amd import ba_bench as _bb

@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the judged profile artefacts on the GPU box (run through gpurun) into gpurun_out/profiles_rNN/.
-# usage: bash tools/collect_profiles.sh r02
+# usage: bash tools/collect_profiles.sh r03
 set -e
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -35,4 +35,8 @@ bash $ROOT/tools/pmc_ba.sh $OUT/pmc_ba_${TAG}.txt || true
 rm -rf /tmp/prof_st && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_st -- python3 $ROOT/tools/setup_prof.py > $OUT/setup_${TAG}.txt 2>/dev/null || true
 python3 $ROOT/tools/summarize_stats.py /tmp/prof_st 60 | grep -i "structure_rows\|kernel   " >> $OUT/setup_${TAG}.txt || true
 python3 $ROOT/tools/overlap_probe.py 2>/dev/null | tail -2 > $OUT/schur_band_overlap_${TAG}.txt || true
+# 7. round 3: the band solve's panel-step modes A/B in one process (2 = launch pairs on two streams, 3 = persistent window
+#    kernel), and the first optimize() of a process by phase
+python3 $ROOT/tools/band_modes_probe.py 2 3 2>/dev/null | grep '^{' > $OUT/band_modes_${TAG}.txt || true
+python3 $ROOT/tools/cold_phases.py 2>/dev/null | grep '^{' > $OUT/cold_phases_${TAG}.txt || true
 ls -la $OUT

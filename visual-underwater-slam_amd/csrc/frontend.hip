@@ -87,6 +87,47 @@ __device__ __forceinline__ int fast_score_strip(const uint32_t (&r)[7][3]) {
   return max(best_bright, -best_dark) - 1;
 }
 
+// The same score on PACKED 16-bit pairs (round 3).  Lane pair (b, 255 - b) of every circle pixel --
+// one v_perm_b32 from the row dword and its complement -- so that ONE v_pk_min_i16 chain serves bright and dark arcs:
+//   min over an arc of b        = p + (bright arc's min d),      min over an arc of (255 - b) = 255 - max b,
+// and the windows double instead of tripling: w2, w4, w8, then w9 = min(w8[k], v[k+8]) -- 4 packed ops per position
+// instead of 2 x (min3 + min3/max) on scalars.  score = max(max_k w9.lo - p, max_k w9.hi - (255 - p)) - 1: identical.
+typedef short short2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int fast_score_pk(const uint32_t (&r)[7][3]) {     // pixel = byte 4 of the 12-byte windows
+  constexpr int DX[16] = {0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3, -3, -3, -2, -1};
+  constexpr int DY[16] = {-3, -3, -2, -1, 0, 1, 2, 3, 3, 3, 2, 1, 0, -1, -2, -3};
+  const int p = byte_of(r[3][1], 0);
+  uint32_t nr[7][2];
+#pragma unroll
+  for (int k = 0; k < 7; ++k) {
+    nr[k][0] = ~r[k][0];
+    nr[k][1] = ~r[k][1];
+  }
+  short2_t v[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    const int pos = 4 + DX[k], row = 3 + DY[k], dw = pos >> 2, by = pos & 3;
+    // v_perm_b32: selector bytes 0-3 address src1 (the row), 4-7 src0 (its complement), 0x0c = constant zero
+    const uint32_t sel = (uint32_t)by | (0x0cu << 8) | ((uint32_t)(4 + by) << 16) | (0x0cu << 24);
+    v[k] = __builtin_bit_cast(short2_t, __builtin_amdgcn_perm(nr[row][dw], r[row][dw], sel));
+  }
+  short2_t w2[16], w4[16], w8[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w2[k] = __builtin_elementwise_min(v[k], v[(k + 1) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w4[k] = __builtin_elementwise_min(w2[k], w2[(k + 2) & 15]);
+#pragma unroll
+  for (int k = 0; k < 16; ++k) w8[k] = __builtin_elementwise_min(w4[k], w4[(k + 4) & 15]);
+  short2_t best = __builtin_elementwise_min(w8[0], v[8]);
+#pragma unroll
+  for (int k = 1; k < 16; ++k) best = __builtin_elementwise_max(best, __builtin_elementwise_min(w8[k], v[(k + 8) & 15]));
+  return max((int)best.x - p, (int)best.y - (255 - p)) - 1;
+}
+
+#ifndef VUS_FAST_PK
+#define VUS_FAST_PK 1
+#endif
+
 template <int E>
 __device__ __forceinline__ bool nms_keep(const uint32_t (&c)[3][3]) {
   // pixel E of the strip = byte 4+E of the 12-byte windows; strict maximum of its 8 neighbours
@@ -261,7 +302,11 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
         r[k][1] = __builtin_amdgcn_alignbyte(c, b, e);
         r[k][2] = c >> (8 * e);
       }
+#if VUS_FAST_PK
+      const int sc = fast_score_pk(r);
+#else
       const int sc = fast_score_strip<0>(r);
+#endif
       if (sc >= thr) score8[ent] = (uint8_t)sc;
     }
     __syncthreads();
