@@ -124,8 +124,12 @@ __device__ __forceinline__ int fast_score_pk(const uint32_t (&r)[7][3]) {     //
   return max((int)best.x - p, (int)best.y - (255 - p)) - 1;
 }
 
+// Measured (MI355X, configs[1], A/B builds in one gpurun call, twice): fast_detect 6.23 / 6.25 ms packed against
+// 6.17 / 6.17 ms with the scalar v_min3 / v_max3 windows of fast_score_strip -- 95 packed instructions (64 v_pk_min_i16,
+// 15 v_pk_max_i16, 16 v_perm_b32) + 17 v_not do not issue faster than the ~160 scalar ones they replace.  Bit-exact
+// either way (tests/test_frontend_gpu.py); the scalar form stays the default.
 #ifndef VUS_FAST_PK
-#define VUS_FAST_PK 1
+#define VUS_FAST_PK 0
 #endif
 
 template <int E>
