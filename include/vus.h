@@ -308,7 +308,8 @@ int vus_ba_add_diag(double* Sband, int n_poses, int band, double value, void* st
  * vus_ba_pack_observations: rows (obs_pose[i], obs_point[i], meas[i]) in any order -> the L-order arrays (sorted by
  *   point, then pose) meas_L / obs_pose_L / obs_point_L / point_ptr [n_points+1] / obs_ppos, the P-order arrays
  *   pose_ptr [n_poses+1] / pobs_lidx, and perm (L-order row -> input row).  flags[0] (device): bit 0 = two factors
- *   between the same pose and landmark, bit 1 = an index out of range.
+ *   between the same pose and landmark, bit 1 = an index out of range.  band[0] (device, may be NULL): the widest
+ *   keyframe span of a landmark = the half-bandwidth, in pose blocks, of the reduced camera system.
  * vus_exclusive_scan_i32: out[i] = in[0] + .. + in[i-1] for i <= n as 32-bit offsets, total[0] = the whole sum in
  *   64 bits (so that the caller can refuse a sum the offsets cannot hold); n up to a few hundred thousand. */
 long long vus_pack_work_bytes(int n);
@@ -318,7 +319,7 @@ int vus_lookup_keys(const int64_t* sorted_keys, int m, const int64_t* queries, i
                     void* stream);
 int vus_ba_pack_observations(const int* obs_pose, const int* obs_point, const double* meas, int n_obs, int n_poses,
                              int n_points, double* meas_L, int* obs_pose_L, int* obs_point_L, int* point_ptr,
-                             int* obs_ppos, int* pose_ptr, int* pobs_lidx, int* perm, int* flags, void* work,
+                             int* obs_ppos, int* pose_ptr, int* pobs_lidx, int* perm, int* flags, int* band, void* work,
                              long long work_bytes, void* stream);
 int vus_exclusive_scan_i32(const int* in, int n, int* out, long long* total, void* stream);
 
@@ -367,6 +368,7 @@ int vus_ba_band_solve_multi_split(double* Sband, int n_nodes, int band, double* 
  *   VUS_TUNE_CB_MAX_WG   cap on the cooperating workgroups of the back-substitution (0 = from the occupancy query). */
 #define VUS_TUNE_BAND_MODE 0
 #define VUS_TUNE_CB_MAX_WG 1
+#define VUS_TUNE_LAST_BAND_MODE 2   /* read-only (vus_ba_get_tuning): how the most recent factorisation was issued, 0..3 */
 int vus_ba_set_tuning(int knob, int value);
 int vus_ba_get_tuning(int knob);
 

@@ -48,11 +48,12 @@ int vus_lookup_keys_cpu(const int64_t* sorted_keys, int m, const int64_t* querie
 
 int vus_ba_pack_observations_cpu(const int* obs_pose, const int* obs_point, const double* meas, int n_obs, int n_poses,
                                  int n_points, double* meas_L, int* obs_pose_L, int* obs_point_L, int* point_ptr,
-                                 int* obs_ppos, int* pose_ptr, int* pobs_lidx, int* perm, int* flags, void* work,
+                                 int* obs_ppos, int* pose_ptr, int* pobs_lidx, int* perm, int* flags, int* band, void* work,
                                  long long work_bytes) {
   (void)work; (void)work_bytes;
   if (n_obs < 0 || n_poses < 1 || n_points < 0 || !point_ptr || !pose_ptr || !flags) return VUS_E_INVALID;
   flags[0] = 0;
+  if (band) band[0] = 0;
   memset(point_ptr, 0, sizeof(int) * (size_t)(n_points + 1));
   memset(pose_ptr, 0, sizeof(int) * (size_t)(n_poses + 1));
   if (n_obs == 0) return VUS_OK;
@@ -78,6 +79,12 @@ int vus_ba_pack_observations_cpu(const int* obs_pose, const int* obs_point, cons
   }
   for (int j = 0; j < n_points; ++j) point_ptr[j + 1] += point_ptr[j];
   for (int i = 0; i < n_poses; ++i) pose_ptr[i + 1] += pose_ptr[i];
+  if (band)
+    for (int j = 0; j < n_points; ++j)
+      if (point_ptr[j + 1] > point_ptr[j]) {
+        int span = obs_pose_L[point_ptr[j + 1] - 1] - obs_pose_L[point_ptr[j]];
+        if (span > band[0]) band[0] = span;
+      }
   /* P-order: L-order rows counting-sorted by pose (stable: points ascend inside a pose) */
   int* fill = (int*)malloc(sizeof(int) * (size_t)n_poses);
   memcpy(fill, pose_ptr, sizeof(int) * (size_t)n_poses);

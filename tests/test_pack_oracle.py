@@ -24,12 +24,13 @@ def oracle_pack(O, op, ol, meas, n_poses, n_points):
     out = dict(meas=np.zeros((n, 3)), obs_pose=np.zeros(n, np.int32), obs_point=np.zeros(n, np.int32),
                point_ptr=np.zeros(n_points + 1, np.int32), obs_ppos=np.zeros(n, np.int32),
                pose_ptr=np.zeros(n_poses + 1, np.int32), pobs_lidx=np.zeros(n, np.int32), perm=np.zeros(n, np.int32))
-    flags = np.zeros(1, np.int32)
+    flags, band = np.zeros(1, np.int32), np.zeros(1, np.int32)
     rc = O.lib().vus_ba_pack_observations_cpu(_p(op), _p(ol), _p(np.ascontiguousarray(meas)), n, n_poses, n_points, _p(out["meas"]),
                                               _p(out["obs_pose"]), _p(out["obs_point"]), _p(out["point_ptr"]), _p(out["obs_ppos"]),
-                                              _p(out["pose_ptr"]), _p(out["pobs_lidx"]), _p(out["perm"]), _p(flags), None,
+                                              _p(out["pose_ptr"]), _p(out["pobs_lidx"]), _p(out["perm"]), _p(flags), _p(band), None,
                                               ctypes.c_longlong(0))
     assert rc == 0
+    out["band"] = int(band[0])
     return out, int(flags[0])
 
 
@@ -42,6 +43,7 @@ def test_oracle_pack_equals_the_torch_construction(oracle, shape):
     assert flags == 0
     for k in ("meas", "obs_pose", "obs_point", "point_ptr", "obs_ppos", "pose_ptr", "pobs_lidx", "perm"):
         assert np.array_equal(got[k], ref[k].numpy()), k
+    assert got["band"] == ba_pack.build_structure(ref)["band"]
 
 
 def test_oracle_pack_flags_duplicates_and_bad_indices(oracle):
@@ -84,6 +86,7 @@ def test_device_pack_equals_oracle_and_torch(gpu, oracle, shape):
     assert flags == 0
     for k in ("meas", "obs_pose", "obs_point", "point_ptr", "obs_ppos", "pose_ptr", "pobs_lidx", "perm"):
         assert np.array_equal(got[k].cpu().numpy(), exp[k]), k
+    assert got["band"] == exp["band"]
 
 
 @pytest.mark.gpu

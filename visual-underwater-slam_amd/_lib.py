@@ -42,7 +42,7 @@ SIGNATURES = {
     # graph packing (csrc/pack.hip)
     "vus_keys_to_indices": [_P, c_int, _P, _P, _P, _P, ctypes.c_longlong, _P],
     "vus_lookup_keys": [_P, c_int, _P, c_int, _P, _P, _P],
-    "vus_ba_pack_observations": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _P],
+    "vus_ba_pack_observations": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _P],
     "vus_exclusive_scan_i32": [_P, c_int, _P, _P, _P],
     # navigation factors
     "vus_nav_linearize": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
@@ -54,7 +54,7 @@ SIGNATURES = {
     "vus_ba_set_tuning": [c_int, c_int],
 }
 
-TUNE_BAND_MODE, TUNE_CB_MAX_WG = 0, 1       # VUS_TUNE_* of include/vus.h
+TUNE_BAND_MODE, TUNE_CB_MAX_WG, TUNE_LAST_BAND_MODE = 0, 1, 2       # VUS_TUNE_* of include/vus.h
 
 
 class VusError(RuntimeError):

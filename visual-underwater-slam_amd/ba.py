@@ -14,6 +14,7 @@ from ctypes import c_double, c_int, c_void_p
 from dataclasses import dataclass, field
 from typing import List, Optional
 
+import numpy as np
 import torch
 
 from . import _lib, ba_pack
@@ -87,7 +88,7 @@ def build_structure_device(pk):
         band = int((last - first).max().item())
     if band > STRUCTURE_MAX_BAND:
         return ba_pack.build_structure(pk)
-    dev = op.device
+    dev = pk["obs_pose"].device
     p = _lib.ptr
     # only the index arrays of the problem are read
     cp = _CProblem(nP, pk["n_points"], n_obs, 0, None, 1.0, None, p(pk["obs_pose"]), p(pk["obs_point"]),
@@ -152,7 +153,10 @@ class StereoBAProblem:
         else:
             self.prior_pose = to_dev(prior_pose, torch.int32)
             self.prior_T = to_dev(prior_T, torch.float64).reshape(-1, 12)
-            self.prior_w = (1.0 / to_dev(prior_sigmas, torch.float64).reshape(-1, 6)).contiguous()
+            # reciprocal on the host: a torch elementwise kernel used once here costs the first call of a process ~20 ms
+            # of lazily loaded code objects (tools/cold_phases.py)
+            ps = prior_sigmas.detach().cpu().numpy() if torch.is_tensor(prior_sigmas) else prior_sigmas
+            self.prior_w = to_dev(1.0 / np.asarray(ps, dtype=np.float64).reshape(-1, 6), torch.float64)
         n_pr = self.prior_pose.numel()
         p = _lib.ptr
         self.c_problem = _CProblem(self.n_poses, self.n_points, self.n_obs, n_pr, p(self.K), 1.0 / self.sigma,

@@ -63,9 +63,15 @@ def roofline(prob, stage_ms):
     # launch pairs shared by both halves, then the middle system's fused launches, one per 8-pose panel
     m = ((nN - B) // 2 // PB) * PB if B > 0 else 0
     split = m >= PB and nN >= 2 * B + 64
+    # how the factorisation was really issued (the library records it): 3 = the persistent window kernel (ONE launch for
+    # both halves, one for the middle system), 2 = a (TRSM, SYRK) launch pair per panel and HALF on two streams, 1 = one
+    # pair per panel shared by both halves, 0 = one fused launch per panel
+    from . import _lib
+    mode = int(_lib.load().vus_ba_get_tuning(_lib.TUNE_LAST_BAND_MODE))
     if split:
         n_mid = nN - 2 * m
-        launches = 2 * (m // PB) + (n_mid + PB - 1) // PB
+        mid = (n_mid + PB - 1) // PB
+        launches = {3: 2, 2: 4 * (m // PB) + mid, 1: 2 * (m // PB) + mid}.get(mode, 2 * (m // PB) + mid)
     ms = stage_ms
     per_launch_us = 1e3 * ms["band_solve"] / launches           # includes the back-substitution's share
     stages = {
@@ -83,7 +89,8 @@ def roofline(prob, stage_ms):
                                "share the launches), each as long as tile (0,0)'s dependent chain / one round of update tiles"},
     }
     dom = max(("linearize", "schur", "band_solve"), key=lambda k: ms[k])
-    top = {"kernel": {"band_solve": "chol_syrk_kernel" if split else "chol_trsm_update_kernel", "schur": "schur_rows_kernel",
+    band_kernel = "chol_window_kernel" if (split and mode == 3) else ("chol_syrk_kernel" if split else "chol_trsm_update_kernel")
+    top = {"kernel": {"band_solve": band_kernel, "schur": "schur_rows_kernel",
                       "linearize": "lin_points_kernel"}[dom],
            "stage": dom, "bound": stages[dom]["bound"], "achieved": stages[dom]["achieved"], "peak": stages[dom]["peak"],
            "unit": stages[dom]["unit"], "frac": stages[dom]["frac"], "traffic": None}
@@ -96,9 +103,12 @@ def roofline(prob, stage_ms):
     except Exception:
         pass
     if dom == "band_solve":
-        top.update({"launches_per_solve": launches, "avg_launch_us": round(per_launch_us, 2),
+        top.update({"launches_per_solve": launches, "avg_launch_us": round(per_launch_us, 2), "band_mode": mode,
                     "flops_per_launch": round(fl / launches), "note": "f64 flops of the band Cholesky per launch / "
-                    "(band_solve stage time / launches); peak = f64 matrix peak (v_mfma_f64_16x16x4_f64)"})
+                    "(band_solve stage time / launches): the stage time (HIP events around the whole solve) includes the "
+                    "back-substitution and the split's copies, so `achieved` is a lower bound of the kernel's own rate "
+                    "(profiles/kernel_stats_ba_rNN.txt has the kernel's average duration); peak = f64 matrix peak "
+                    "(v_mfma_f64_16x16x4_f64).  A latency chain, not a flop problem: DESIGN.md section 4"})
     return top, stages
 
 

@@ -60,14 +60,15 @@ def pack_observations_device(obs_pose, obs_point, meas, n_poses, n_points):
            "obs_point": torch.empty(n_obs, **i32), "point_ptr": torch.empty(int(n_points) + 1, **i32),
            "obs_ppos": torch.empty(n_obs, **i32), "pose_ptr": torch.empty(int(n_poses) + 1, **i32),
            "pobs_lidx": torch.empty(n_obs, **i32), "perm": torch.empty(n_obs, **i32)}
-    flags = torch.empty(1, **i32)
+    flags = torch.empty(2, **i32)                  # [flags, band]
     nbytes = int(_lib.load().vus_pack_work_bytes(n_obs))
     work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     p = _lib.ptr
     _lib.call("vus_ba_pack_observations", p(obs_pose), p(obs_point), p(meas), n_obs, int(n_poses), int(n_points),
               p(out["meas"]), p(out["obs_pose"]), p(out["obs_point"]), p(out["point_ptr"]), p(out["obs_ppos"]),
-              p(out["pose_ptr"]), p(out["pobs_lidx"]), p(out["perm"]), p(flags), p(work), nbytes, _lib.current_stream_ptr())
-    f = int(flags.item())
+              p(out["pose_ptr"]), p(out["pobs_lidx"]), p(out["perm"]), p(flags), p(flags[1:]), p(work), nbytes,
+              _lib.current_stream_ptr())
+    f, out["band"] = (int(v) for v in flags.tolist())
     if f & 2:
         raise IndexError("a stereo factor refers to a pose or landmark index outside the problem")
     if f & 1:

@@ -42,6 +42,7 @@ namespace {
 struct Knobs {
   std::atomic<int> band_mode{-1};
   std::atomic<int> cb_max_wg{0};
+  std::atomic<int> last_mode{-1};      // how the last factorisation of this process was issued (0..3): diagnostics / bench
   Knobs() {
     if (const char* e = getenv("VUS_BAND_MODE")) band_mode = atoi(e);
     if (const char* e = getenv("VUS_CB_MAX_WG")) cb_max_wg = atoi(e);
@@ -1577,10 +1578,10 @@ __device__ __forceinline__ void cb_load_inv(const double* __restrict__ Sb, int b
   // them).  One per-lane base, the rest of every address is the same for all lanes; all 48 loads are issued before
   // the first result is looked at.
   const double* safe = Sb + bandidx::cb_inv_safe(band, k0);
+  const double* col = Sb + bandidx::cb_inv_base(band, k0, lane);      // may point in front of the panel: never used alone
 #pragma unroll
   for (int r = 0; r < NB; ++r) {
-    const long long o_el = bandidx::cb_inv(band, k0, nb, lane, r);
-    const double* src = o_el >= 0 ? Sb + o_el : safe;
+    const double* src = bandidx::cb_inv_stored(nb, lane, r) ? col + bandidx::cb_inv_delta(band, r) : safe;
     Lp[r] = *src;
   }
 #pragma unroll
@@ -2591,9 +2592,13 @@ int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream
   //     (chol_window_kernel); the automatic choice wherever it applies (window_applicable).
   {
     const int m = g_knobs.band_mode.load(std::memory_order_relaxed);
-    if ((m < 0 || m == 3) && window_applicable(S, band, full ? n : n_elim)) return window_launch(S, band, full ? n : n_elim, n_rhs, st);
+    if ((m < 0 || m == 3) && window_applicable(S, band, full ? n : n_elim)) {
+      g_knobs.last_mode = 3;
+      return window_launch(S, band, full ? n : n_elim, n_rhs, st);
+    }
     if (m == 0 || m == 1 || (m == 2 && S.count == 2 && st2)) mode = m;
   }
+  g_knobs.last_mode = mode;
   BandSet one[2];
   hipStream_t sts[2] = {st, st2};
   int n_sets = 1;
@@ -2984,6 +2989,7 @@ extern "C" int vus_ba_set_tuning(int knob, int value) {
 extern "C" int vus_ba_get_tuning(int knob) {
   if (knob == VUS_TUNE_BAND_MODE) return g_knobs.band_mode.load();
   if (knob == VUS_TUNE_CB_MAX_WG) return g_knobs.cb_max_wg.load();
+  if (knob == VUS_TUNE_LAST_BAND_MODE) return g_knobs.last_mode.load();
   return vus::fail(VUS_E_INVALID, "unknown tuning knob %d", knob);
 }
 

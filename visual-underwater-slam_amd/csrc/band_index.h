@@ -152,13 +152,19 @@ VUS_HD long long cb_diag_pivot(int band, int k0, int nb, int lane) {
 // cb_load_inv: element (row r, column lane) of the INVERTED diagonal panel (band >= PB - 1 only); masked lanes read
 // cb_inv_safe = the panel's first element
 VUS_HD long long cb_inv_safe(int band, int k0) { return 36ll * k0 * (band + 1); }
-VUS_HD long long cb_inv(int band, int k0, int nb, int lane, int r) {
+// = cb_inv_base (per lane: element (row 0 of the panel, column lane), which for lane >= 6 lies in front of the panel and
+// is only ever used together with a row delta that brings it back inside) + cb_inv_delta (per row, the same for every
+// lane: the kernel keeps ONE per-lane pointer and adds wave-uniform offsets -- 48 loads, no per-element 64-bit address
+// arithmetic on the sweep's critical path)
+VUS_HD long long cb_inv_base(int band, int k0, int lane) {
   const int ln = lane < NB ? lane : 0;
   const int c6 = ln / 6, cm = ln - 6 * c6;
-  if (!(r < nb && lane <= r)) return -1;
-  const long long col = 36ll * k0 * (band + 1) + (cm - 36 * c6);          // element (row 0 of the panel, column ln)
-  const long long stride = 36ll * (band + 2);                            // one block row down, same block column
-  return col + ((r / 6) * stride + 6 * (r % 6));
+  return 36ll * k0 * (band + 1) + (cm - 36 * c6);
+}
+VUS_HD long long cb_inv_delta(int band, int r) { return (long long)(r / 6) * (36ll * (band + 2)) + 6 * (r % 6); }
+VUS_HD bool cb_inv_stored(int nb, int lane, int r) { return r < nb && lane <= r; }
+VUS_HD long long cb_inv(int band, int k0, int nb, int lane, int r) {
+  return cb_inv_stored(nb, lane, r) ? cb_inv_base(band, k0, lane) + cb_inv_delta(band, r) : -1;
 }
 // row c of the transposed block (8 P + kk, 8 P - 8 G - 8 + a): 6 contiguous doubles
 VUS_HD long long cb_rows(int band, int n_poses, int P, int G, int kk, int a, int c) {

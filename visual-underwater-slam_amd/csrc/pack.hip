@@ -111,6 +111,15 @@ __global__ void point_ptr_kernel(const unsigned long long* __restrict__ sk, int 
   if (j <= n_points) point_ptr[j] = lower_bound_u64(sk, n, (unsigned long long)j * (unsigned long long)n_poses);
 }
 
+// widest keyframe span of a landmark = half-bandwidth (in pose blocks) of the reduced camera system
+__global__ void band_kernel(const int* __restrict__ point_ptr, const int* __restrict__ obs_pose_L, int n_points,
+                            int* __restrict__ band) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_points) return;
+  const int a0 = point_ptr[j], a1 = point_ptr[j + 1];
+  if (a1 > a0) atomicMax(band, obs_pose_L[a1 - 1] - obs_pose_L[a0]);
+}
+
 __global__ void pose_ptr_kernel(const int* __restrict__ sorted_pose, int n, int n_poses, int* __restrict__ pose_ptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i <= n_poses) pose_ptr[i] = lower_bound_i32(sorted_pose, n, i);
@@ -244,11 +253,12 @@ extern "C" int vus_lookup_keys(const int64_t* sorted_keys, int m, const int64_t*
 extern "C" int vus_ba_pack_observations(const int* obs_pose, const int* obs_point, const double* meas, int n_obs,
                                         int n_poses, int n_points, double* meas_L, int* obs_pose_L, int* obs_point_L,
                                         int* point_ptr, int* obs_ppos, int* pose_ptr, int* pobs_lidx, int* perm, int* flags,
-                                        void* work, long long work_bytes, void* stream) {
+                                        int* band, void* work, long long work_bytes, void* stream) {
   VUS_REQUIRE(n_obs >= 0 && n_poses >= 1 && n_points >= 0, "n_obs=%d n_poses=%d n_points=%d", n_obs, n_poses, n_points);
   VUS_REQUIRE(point_ptr && pose_ptr && flags, "null buffer");
   hipStream_t st = vus::as_stream(stream);
   VUS_CHECK_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
+  if (band) VUS_CHECK_HIP(hipMemsetAsync(band, 0, sizeof(int), st));
   if (n_obs == 0) {
     VUS_CHECK_HIP(hipMemsetAsync(point_ptr, 0, sizeof(int) * (size_t)(n_points + 1), st));
     VUS_CHECK_HIP(hipMemsetAsync(pose_ptr, 0, sizeof(int) * (size_t)(n_poses + 1), st));
@@ -276,6 +286,7 @@ extern "C" int vus_ba_pack_observations(const int* obs_pose, const int* obs_poin
   VUS_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tb, key, sk, iota, perm, (size_t)n, 0, kbits, st));
   gather_L_kernel<<<cdiv(n, 256), 256, 0, st>>>(sk, perm, meas, n, n_poses, meas_L, obs_pose_L, obs_point_L, flags);
   point_ptr_kernel<<<cdiv(n_points + 1, 256), 256, 0, st>>>(sk, n, n_poses, n_points, point_ptr);
+  if (band && n_points > 0) band_kernel<<<cdiv(n_points, 256), 256, 0, st>>>(point_ptr, obs_pose_L, n_points, band);
   // P-order: a STABLE sort of the L-order rows by pose keeps the points ascending inside every pose
   size_t tb2 = tb;
   VUS_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tb2, reinterpret_cast<const unsigned int*>(obs_pose_L),
