@@ -151,6 +151,19 @@ void sweep_window(Sweep& S, int n_elim) {
         S.expect("win_row", off, blk(band, PB * I + (item >> 3) / 6, PB * J + (item & 7)) + 6 * ((item >> 3) % 6), p, slot, item);
         if (off >= 0 && off % 2 != 0) S.fail("win_row: not 16-byte aligned", off, 6, p, slot, item);
       }
+      if (I + 1 < NT && J + 1 <= I + 1)     // the same tile one step down the diagonal: every address + win_step_stride
+        for (int item = 0; item < 6 * UTP * PB; ++item) {
+          const long long a = win_row(band, n, PB * I, PB * J, item >> 3, item & 7);
+          const long long b = win_row(band, n, PB * (I + 1), PB * (J + 1), item >> 3, item & 7);
+          if (a >= 0 && b >= 0) S.expect("win_step_stride/win_row", b, a + win_step_stride(band), p, slot, item);
+          if (p + 1 < NE && I > p) {
+            const int k1 = k0 + PB, pb1 = n - k1 < PB ? n - k1 : PB;
+            int il1 = k1 + pb1 - 1 + band;
+            if (il1 > n - 1) il1 = n - 1;
+            const long long xa = solved_item(band, k0, pb, i_last, PB * I, item), xb = solved_item(band, k1, pb1, il1, PB * (I + 1), item);
+            if (xa >= 0 && xb >= 0) S.expect("win_step_stride/solved_item", xb, xa + win_step_stride(band), p, slot, item);
+          }
+        }
       if (p < NE && I > p)
         for (int item = 0; item < UTP * PB * 6; ++item) {
           const long long off = solved_item(band, k0, pb, i_last, PB * I, item);

@@ -43,9 +43,11 @@ struct Knobs {
   std::atomic<int> band_mode{-1};
   std::atomic<int> cb_max_wg{0};
   std::atomic<int> last_mode{-1};      // how the last factorisation of this process was issued (0..3): diagnostics / bench
+  std::atomic<int> win_pad{1};         // VUS_WIN_PAD=0: no padding blocks beside the critical workgroups (A/B timing)
   Knobs() {
     if (const char* e = getenv("VUS_BAND_MODE")) band_mode = atoi(e);
     if (const char* e = getenv("VUS_CB_MAX_WG")) cb_max_wg = atoi(e);
+    if (const char* e = getenv("VUS_WIN_PAD")) win_pad = atoi(e);
   }
 };
 Knobs g_knobs;
@@ -1945,6 +1947,23 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     s_rhs[e] = c < 6 * n ? ld_sc1(B.y + (size_t)q * ystride + c) : 0.0;
   }
   __syncthreads();
+  // Per-thread addresses of the three tiles every step touches -- sub-diagonal tile (I, I-1) and diagonal tile (I, I) by
+  // row segments, solved rows X of block row I -- computed ONCE for I = 1; they advance by win_step_stride per step
+  // (band_index.h; the CPU sweep checks that against win_row / solved_item).  What varies is the matrix's end only.
+  const unsigned step_bytes = (unsigned)(8 * bandidx::win_step_stride(band));
+  unsigned fa_off[2], fd_off[2], xs_off[2];
+  int f_ii[2], x_ii[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int item = tid + 256 * u;
+    const bool in = item < WIN_ITEMS;
+    f_ii[u] = (item >> 3) / 6;
+    x_ii[u] = item / (6 * PB);
+    // as if the matrix had no end (n = INT_MAX): the end is tested per step
+    fa_off[u] = in ? win_off(bandidx::win_row(band, 0x7FFFFFFF, PB, 0, item >> 3, item & 7)) : WIN_OOB;
+    fd_off[u] = in ? win_off(bandidx::win_row(band, 0x7FFFFFFF, PB, PB, item >> 3, item & 7)) : WIN_OOB;
+    xs_off[u] = in ? win_off(bandidx::solved_item(band, 0, PB, 0x7FFFFFFF, PB, item)) : WIN_OOB;
+  }
   bool ok = true;
 #ifdef VUS_TIMING
   unsigned long long wt[10];
@@ -1955,7 +1974,6 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
   for (int p = 0; p < NE; ++p) {
     const int k0 = PB * p;
     const int pb = min(PB, n - k0), nb = 6 * pb;
-    const int i_last = min(n - 1, k0 + pb - 1 + band);
     VUS_WT(0);
     panel_factor<true, true>(B.Sb, n, band, k0, B.y, ystride, n_rhs, B.status, reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad,
                              sL, s_rhs, pb, sL, s_z);
@@ -1975,8 +1993,17 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
         if (!s_go) { ok = false; break; }
       }
       VUS_WT(4);
-      win_fetch_tile(rsS, band, n, PB * I, k0, fa);
-      win_fetch_tile(rsS, band, n, PB * I, PB * I, fb);
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const bool inside = PB * I + f_ii[u] < n;             // the tile's rows past the matrix's end read as zero
+        const unsigned oa = (inside && fa_off[u] != WIN_OOB) ? fa_off[u] + step_bytes * (unsigned)p : WIN_OOB;
+        const unsigned od = (inside && fd_off[u] != WIN_OOB) ? fd_off[u] + step_bytes * (unsigned)p : WIN_OOB;
+#pragma unroll
+        for (int h = 0; h < 3; ++h) {
+          fa.v[u][h] = ld16_sc1(rsS, oa == WIN_OOB ? WIN_OOB : oa + 16 * h);
+          fb.v[u][h] = ld16_sc1(rsS, od == WIN_OOB ? WIN_OOB : od + 16 * h);
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 2; ++u) {       // NB * n_rhs <= 384 right-hand-side elements
         const int e = tid + 256 * u;
@@ -2016,7 +2043,19 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     VUS_WT(5);
     solve_rows<true>(1, Xi, Xi, sL, sM);         // X of block row p+1
     VUS_WT(6);
-    win_store_xtile(rsS, band, k0, pb, i_last, PB * I, Xi);      // on its way to memory while the update below runs
+    // the solved rows, on their way to memory while the update below runs (same items as win_store_xtile)
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int item = tid + 256 * u;
+      if (item >= WIN_ITEMS) continue;
+      const bool inside = PB * I + x_ii[u] < n;
+      const unsigned o = (inside && xs_off[u] != WIN_OOB) ? xs_off[u] + step_bytes * (unsigned)p : WIN_OOB;
+      const int rem = item - 6 * PB * x_ii[u];
+      const int kk = rem / 6, c = rem - 6 * kk;
+      const double* src = Xi + (6 * x_ii[u]) * ULD + 6 * kk + c;
+#pragma unroll
+      for (int h = 0; h < 3; ++h) st16_sc1(rsS, o == WIN_OOB ? WIN_OOB : o + 16 * h, d2a_t{src[(2 * h) * ULD], src[(2 * h + 1) * ULD]});
+    }
     {
       // next diagonal tile -= X X^T: its six lower MFMA tiles, at most two per wave; every element of Xn belongs to
       // one lane
@@ -2241,12 +2280,17 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
   }
 }
 
-__global__ __launch_bounds__(256, 2) void chol_window_kernel(WinSet S, int band, int NE, int n_rhs) {
+// Block map: blocks 0 .. count-1 are the critical workgroups; blocks pad0 .. pad0+count-1 exit at once; the rest are the
+// window slots in order.  pad0 = the number of CUs: with two workgroups per CU and blocks dealt to CUs in order, block
+// b + n_cu is the one that would share a CU with block b, so the padding leaves each critical workgroup a compute unit
+// (its LDS bandwidth, its issue slots) to itself.  Placement is the hardware's business: if it differs, only speed does.
+__global__ __launch_bounds__(256, 2) void chol_window_kernel(WinSet S, int band, int NE, int n_rhs, int pad0) {
   extern __shared__ __attribute__((aligned(16))) double win_smem[];
   __shared__ int s_bad, s_go;
   const int bid = blockIdx.x;
+  if (bid >= pad0 && bid < pad0 + S.count) return;
   if (bid < S.count) win_critical(S.s[bid], band, NE, n_rhs, win_smem, s_bad, s_go);
-  else win_bulk(S, bid - S.count, band, NE, n_rhs, win_smem, s_go);
+  else win_bulk(S, bid - S.count - (bid >= pad0 ? S.count : 0), band, NE, n_rhs, win_smem, s_go);
   if (threadIdx.x == 0)
     for (int q = 0; q < S.count; ++q)
       if (__hip_atomic_load(S.s[q].F + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) S.s[q].status[0] = -1;
@@ -2550,7 +2594,7 @@ bool window_applicable(const BandSet& S, int band, int n_elim) {
   for (int q = 0; q < S.count; ++q)
     if (!S.s[q].win_pub || !S.s[q].win_F || S.s[q].n != n) return false;
   const int D = (band + PB - 1) / PB, M = D + 1;
-  return M * (M + 1) / 2 + S.count <= window_capacity();
+  return M * (M + 1) / 2 + 2 * S.count <= window_capacity();
 }
 
 int window_launch(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st) {
@@ -2568,7 +2612,9 @@ int window_launch(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t
   const int lds = WIN_LDS_DOUBLES * (int)sizeof(double);
   VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_window_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  chol_window_kernel<<<S.count + M * (M + 1) / 2, 256, lds, st>>>(W, band, NE, n_rhs);
+  const int n_slots = M * (M + 1) / 2, n_cu = device_cu_count();
+  const bool pad = n_cu > 0 && S.count + n_slots > n_cu && g_knobs.win_pad.load(std::memory_order_relaxed) != 0;
+  chol_window_kernel<<<S.count + n_slots + (pad ? S.count : 0), 256, lds, st>>>(W, band, NE, n_rhs, pad ? n_cu : 0x7FFFFFFF);
   VUS_CHECK_LAUNCH("ba_band_window");
   return VUS_OK;
 }

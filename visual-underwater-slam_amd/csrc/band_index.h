@@ -99,6 +99,11 @@ VUS_HD long long win_row(int band, int n, int pi0, int pj0, int Rr, int kk) {
   return ok ? blk(band, i, j) + 6 * rm : -1;
 }
 
+// A tile that moves down the diagonal by one tile (8 poses) keeps every (row-in-tile, block-column distance) and all of
+// its addresses advance by this many doubles: the critical workgroup of chol_window_kernel computes its per-thread
+// offsets ONCE and adds win_step_stride per panel step (checked against win_row / solved_item by the CPU sweep).
+VUS_HD long long win_step_stride(int band) { return 36ll * PB * (band + 1); }
+
 // ---- chol_window: which tile a window slot hosts at panel step p ----------------------------------------------------
 // Tiles are 8 x 8 poses; tile (I, J), J <= I <= J + D, is LIVE during the panel steps [I - D, J] (its first update to its
 // own elimination).  With M = D + 1, tile (I, J) is hosted by the slot of the unordered pair {I mod M, J mod M}: the two
