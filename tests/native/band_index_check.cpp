@@ -145,30 +145,44 @@ void sweep_window(Sweep& S, int n_elim) {
           S.touch("win_scalar", off, 1, p, slot, Rr * 48 + Cc);
           S.expect("win_scalar", off, blk(band, PB * I + Rr / 6, PB * J + Cc / 6) + 6 * (Rr % 6) + Cc % 6, p, slot, Rr * 48 + Cc);
         }
-      for (int item = 0; item < 6 * UTP * PB; ++item) {       // the same tile by 48-byte row segments (16-byte buffer accesses)
-        const long long off = win_row(band, n, PB * I, PB * J, item >> 3, item & 7);
-        S.touch("win_row", off, 6, p, slot, item);
-        S.expect("win_row", off, blk(band, PB * I + (item >> 3) / 6, PB * J + (item & 7)) + 6 * ((item >> 3) % 6), p, slot, item);
-        if (off >= 0 && off % 2 != 0) S.fail("win_row: not 16-byte aligned", off, 6, p, slot, item);
+      // the same tile as the kernel moves it: 16-byte vectors in address order, offset = tile base + the thread's part
+      long long covered = 0;
+      for (int v = 0; v < WIN_VECS + 128; ++v) {              // the fifth round of 256 threads reaches past WIN_VECS
+        const long long off = win_vec(band, n, PB * I, PB * J, v);
+        S.touch("win_vec", off, 2, p, slot, v);
+        if (off < 0) continue;
+        int ii, kk, e;
+        win_vec_pos(v, ii, kk, e);
+        S.expect("win_vec", off, blk(band, PB * I + ii, PB * J + kk) + e, p, slot, v);
+        S.expect("win_vec_base + win_vec_rel", win_vec_base(band, PB * I, PB * J) + win_vec_rel(band, v), off, p, slot, v);
+        if (off % 2 != 0 || e + 1 >= 36) S.fail("win_vec: not a 16-byte vector of one block", off, 2, p, slot, v);
+        if ((unsigned long long)(8 * off) >= 0xFFFFFFF0ull) S.fail("win_vec: past the 32-bit buffer offset", off, 2, p, slot, v);
+        covered += 2;
       }
-      if (I + 1 < NT && J + 1 <= I + 1)     // the same tile one step down the diagonal: every address + win_step_stride
-        for (int item = 0; item < 6 * UTP * PB; ++item) {
-          const long long a = win_row(band, n, PB * I, PB * J, item >> 3, item & 7);
-          const long long b = win_row(band, n, PB * (I + 1), PB * (J + 1), item >> 3, item & 7);
-          if (a >= 0 && b >= 0) S.expect("win_step_stride/win_row", b, a + win_step_stride(band), p, slot, item);
-          if (p + 1 < NE && I > p) {
-            const int k1 = k0 + PB, pb1 = n - k1 < PB ? n - k1 : PB;
-            int il1 = k1 + pb1 - 1 + band;
-            if (il1 > n - 1) il1 = n - 1;
-            const long long xa = solved_item(band, k0, pb, i_last, PB * I, item), xb = solved_item(band, k1, pb1, il1, PB * (I + 1), item);
-            if (xa >= 0 && xb >= 0) S.expect("win_step_stride/solved_item", xb, xa + win_step_stride(band), p, slot, item);
+      for (int v = 0; v < WIN_VECS; ++v) {
+        int ii, kk, e;
+        win_vec_pos(v, ii, kk, e);
+        const bool ok = win_vec_ok(band, n, PB * I, PB * J, ii, kk - ii);
+        if (ok != (win_vec(band, n, PB * I, PB * J, v) >= 0)) S.fail("win_vec_ok disagrees with win_vec", v, 2, p, slot, v);
+      }
+      {   // every stored element of the tile is in exactly one vector
+        long long stored = 0;
+        for (int ii = 0; ii < PB; ++ii)
+          for (int kk = 0; kk < PB; ++kk) {
+            const int i = PB * I + ii, j = PB * J + kk;
+            if (i < n && j <= i && i - j <= band) stored += 36;
           }
-        }
-      if (p < NE && I > p)
-        for (int item = 0; item < UTP * PB * 6; ++item) {
-          const long long off = solved_item(band, k0, pb, i_last, PB * I, item);
-          S.touch("solved_item/window", off, 6, p, slot, item);
-          if (off >= 0 && off % 2 != 0) S.fail("solved_item: not 16-byte aligned", off, 6, p, slot, item);
+        if (stored != covered) S.fail("win_vec: vectors do not cover the tile's stored blocks once", covered, 2, p, slot, (int)stored);
+      }
+      if (p < NE && I > p)      // solved rows of block row I against panel p: the same vectors, blocks transposed
+        for (int v = 0; v < WIN_VECS; ++v) {
+          int ii, kk, e;
+          win_vec_pos(v, ii, kk, e);
+          const long long off = win_vec(band, n, PB * I, k0, v);
+          const long long ref = solved_item(band, k0, pb, i_last, PB * I, ii * 6 * PB + kk * 6 + e / 6);
+          S.touch("win_vec/solved rows", off, 2, p, slot, v);
+          S.expect("win_vec/solved rows", off, ref >= 0 ? ref + e % 6 : -1, p, slot, v);
+          if ((off >= 0) != (ref >= 0)) S.fail("win_vec/solved rows: stored set differs from solved_item", off, 2, p, slot, v);
         }
     }
   }

@@ -710,19 +710,28 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
 // owner wave pulls the 6x6 diagonal block into SGPRs (readlane), factors it in registers, solves its rows
 // against it and publishes them through a ring of three LDS panels; one barrier per block step, and the
 // owner of block s+1 updates that block first and factors it while the other waves finish step s.
+// The 36 doubles of the solved 6x6 block (a wave-uniform LDS address: 18 broadcast ds_read_b128) are all requested
+// before the first multiply-add: left to itself the compiler issues them one by one with a full s_waitcnt behind each
+// (18 dependent LDS round trips per block, ~1.5 k cycles on the panel's critical chain).
 __device__ __forceinline__ void panel_update(double (&blk)[6], const double (&xr)[6], const double* __restrict__ xs) {
+  // two halves of nine loads: all 18 at once cost the window kernel its last free registers (scratch spills)
 #pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    double acc = blk[c];
+  for (int h = 0; h < 2; ++h) {
+    double w[18];
 #pragma unroll
-    for (int k = 0; k < 6; ++k) acc -= xr[k] * xs[6 * c + k];
-    blk[c] = acc;
+    for (int i = 0; i < 18; ++i) w[i] = xs[18 * h + i];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 6; ++k)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) blk[3 * h + c] = __builtin_fma(-xr[k], w[6 * c + k], blk[3 * h + c]);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
 #ifdef VUS_TIMING
 #define VUS_PT(n) const unsigned long long pt##n = __builtin_amdgcn_s_memtime()
-#define VUS_PP() printf("PF %llu %llu %llu\n", pt1 - pt0, pt2 - pt1, pt3 - pt2)
+#define VUS_PP() printf("PF in %llu bar %llu loop %llu bar %llu out %llu\n", pt0 - pt8, pt1 - pt0, pt2 - pt1, pt3 - pt2, pt9 - pt3)
 #else
 #define VUS_PT(n)
 #define VUS_PP()
@@ -740,6 +749,7 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
                                              int& s_bad, const double* lds_tile = nullptr,
                                              const double* lds_rhs = nullptr, int lds_poses = 0,
                                              double* lds_out = nullptr, double* lds_rhs_out = nullptr) {
+  VUS_PT(8);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
@@ -754,9 +764,9 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
     const int kb = wave + 4 * j;
 #pragma unroll
     for (int c = 0; c < 6; ++c) row[j][c] = 0.0;
-    const long long o_row = bandidx::panel_row(band, k0, nb, R, kb);
-    if (o_row >= 0) {
-      const double* src = (FROM_LDS && ii < lds_poses) ? lds_tile + R * LDD + 6 * kb : Sb + o_row;
+    if (bandidx::panel_row_ok(band, nb, R, kb)) {
+      // the offset into the band (64-bit arithmetic) only where the row really comes from memory
+      const double* src = (FROM_LDS && ii < lds_poses) ? lds_tile + R * LDD + 6 * kb : Sb + bandidx::panel_row(band, k0, nb, R, kb);
 #pragma unroll
       for (int c = 0; c < 6; ++c) row[j][c] = src[c];
     }
@@ -833,24 +843,19 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
   VUS_PT(2);
   __syncthreads();
   VUS_PT(3);
-  if (FROM_LDS && threadIdx.x == 0 && k0 == 808) VUS_PP();
   if (threadIdx.x == 0 && s_bad != 0x7FFFFFFF && status[0] == 0) status[0] = s_bad;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int kb = wave + 4 * j;
-    const long long o_row = bandidx::panel_row(band, k0, nb, R, kb);
-    if (o_row >= 0) {
-      double* dst = Sb + o_row;
+    const bool stored = bandidx::panel_row_ok(band, nb, R, kb);
+    if (!PUBLISH && stored) {          // PUBLISH: the caller stores the tile from lds_out, whole cache lines at a time
+      double* dst = Sb + bandidx::panel_row(band, k0, nb, R, kb);
 #pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        const double v = (6 * kb + c <= R) ? row[j][c] : 0.0;   // strict upper part of the diagonal blocks = 0
-        if (PUBLISH) __hip_atomic_store(dst + c, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else dst[c] = v;
-      }
+      for (int c = 0; c < 6; ++c) dst[c] = (6 * kb + c <= R) ? row[j][c] : 0.0;   // strict upper part of the diagonal blocks = 0
     }
     if (PUBLISH && lds_out != nullptr && R < NB) {
 #pragma unroll
-      for (int c = 0; c < 6; ++c) lds_out[R * LDD + 6 * kb + c] = (o_row >= 0 && 6 * kb + c <= R) ? row[j][c] : 0.0;
+      for (int c = 0; c < 6; ++c) lds_out[R * LDD + 6 * kb + c] = (stored && 6 * kb + c <= R) ? row[j][c] : 0.0;
     }
     if (is_rhs && kb < pb) {
 #pragma unroll
@@ -864,6 +869,8 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
       for (int c = 0; c < 6; ++c) lds_rhs_out[(R - nb) * NB + 6 * kb + c] = kb < pb ? row[j][c] : 0.0;
     }
   }
+  VUS_PT(9);
+  if (PUBLISH && threadIdx.x == 0 && k0 == 320) VUS_PP();
 }
 
 // One block-band system handed to the factorisation kernels: storage, right-hand sides [n_rhs, 6 n] (solved in
@@ -1822,83 +1829,60 @@ __device__ __forceinline__ void st16_sc1(rsrc_t r, unsigned byte_off, d2a_t v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)byte_off, 0, 16);
 }
 
-// A 48 x 48 tile as 384 row segments of 6 doubles (2 per thread, the second for half the threads): registers of a fetch
-// that is issued at one point of the program and committed to LDS at another.
-constexpr int WIN_ITEMS = UT * PB;                  // 384
-struct WinFetch {
-  d2a_t v[2][3];
+// A 48 x 48 tile moves as the 1152 16-byte vectors of bandidx::win_vec, in address order: consecutive lanes carry
+// consecutive 16 bytes of a pose row's 2304 contiguous bytes (whole cache lines per wave instruction), 4.5 vectors per
+// thread.  The thread's share of the address arithmetic is done once per launch (WinLane); a tile adds its base.
+constexpr int WIN_VPT = (bandidx::WIN_VECS + 255) / 256;        // 5
+struct WinLane {
+  unsigned rel[WIN_VPT];      // bytes from the tile's base (WIN_OOB: the thread has no such vector)
+  unsigned pk[WIN_VPT];       // LDS index of element e as a natural tile (bits 0-11) / as solved rows (12-23), ii (24-26), kk - ii + 8 (27-30)
 };
-// natural layout: item = (scalar row Rr = item >> 3, block column kk = item & 7)
-__device__ __forceinline__ void win_fetch_tile(rsrc_t rs, int band, int n, int pi0, int pj0, WinFetch& f) {
+struct WinFetch {
+  d2a_t v[WIN_VPT];
+};
+__device__ __forceinline__ WinLane win_lane(int band) {
+  WinLane L;
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int item = threadIdx.x + 256 * u;
-    const unsigned o = item < WIN_ITEMS ? win_off(bandidx::win_row(band, n, pi0, pj0, item >> 3, item & 7)) : WIN_OOB;
+  for (int u = 0; u < WIN_VPT; ++u) {
+    const int v = threadIdx.x + 256 * u;
+    int ii, kk, e;
+    bandidx::win_vec_pos(v, ii, kk, e);
+    const unsigned nat = (unsigned)((6 * ii + e / 6) * LDD + 6 * kk + e % 6);       // elements (r, c), (r, c + 1)
+    const unsigned xt = (unsigned)((6 * ii + e % 6) * ULD + 6 * kk + e / 6);        // elements (r, c), (r + 1, c): transposed blocks
+    L.rel[u] = v < bandidx::WIN_VECS ? (unsigned)(8 * bandidx::win_vec_rel(band, v)) : WIN_OOB;
+    L.pk[u] = nat | xt << 12 | (unsigned)ii << 24 | (unsigned)(kk - ii + 8) << 27;
+  }
+  return L;
+}
+// byte offset of the thread's vector u of tile (pose rows pi0.., pose columns pj0..) in a matrix of n poses, or WIN_OOB
+__device__ __forceinline__ unsigned win_vec_off(const WinLane& L, int u, int band, int n, int pi0, int pj0) {
+  const unsigned base = (unsigned)(8 * bandidx::win_vec_base(band, pi0, pj0));      // modulo 2^32; base + rel is exact
+  const int ii = (int)(L.pk[u] >> 24 & 7), dk = (int)(L.pk[u] >> 27 & 15) - 8;
+  return (L.rel[u] != WIN_OOB && bandidx::win_vec_ok(band, n, pi0, pj0, ii, dk)) ? base + L.rel[u] : WIN_OOB;
+}
+__device__ __forceinline__ void win_fetch(rsrc_t rs, const WinLane& L, int band, int n, int pi0, int pj0, WinFetch& f) {
 #pragma unroll
-    for (int h = 0; h < 3; ++h) f.v[u][h] = ld16_sc1(rs, o == WIN_OOB ? WIN_OOB : o + 16 * h);
+  for (int u = 0; u < WIN_VPT; ++u) f.v[u] = ld16_sc1(rs, win_vec_off(L, u, band, n, pi0, pj0));
+}
+// XT = false: a tile of the matrix, row-major in LDS (stride LDD); XT = true: solved rows, whose blocks are stored
+// transposed (LDS: row-major X, stride ULD).  Vectors the band does not store were fetched as zeros.
+template <bool XT>
+__device__ __forceinline__ void win_commit(const WinLane& L, const WinFetch& f, double* T) {
+#pragma unroll
+  for (int u = 0; u < WIN_VPT; ++u) {
+    if (L.rel[u] == WIN_OOB) continue;
+    double* dst = T + (XT ? L.pk[u] >> 12 & 0xFFF : L.pk[u] & 0xFFF);
+    dst[0] = f.v[u].x;
+    dst[XT ? ULD : 1] = f.v[u].y;
   }
 }
-__device__ __forceinline__ void win_commit_tile(const WinFetch& f, double* T) {     // row-major, stride LDD
+template <bool XT>
+__device__ __forceinline__ void win_store(rsrc_t rs, const WinLane& L, int band, int n, int pi0, int pj0, const double* T) {
 #pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int item = threadIdx.x + 256 * u;
-    if (item >= WIN_ITEMS) continue;
-    double* dst = T + (item >> 3) * LDD + 6 * (item & 7);
-#pragma unroll
-    for (int h = 0; h < 3; ++h) {
-      dst[2 * h] = f.v[u][h].x;
-      dst[2 * h + 1] = f.v[u][h].y;
-    }
-  }
-}
-__device__ __forceinline__ void win_store_tile(rsrc_t rs, int band, int n, int pi0, int pj0, const double* T) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int item = threadIdx.x + 256 * u;
-    if (item >= WIN_ITEMS) continue;
-    const unsigned o = win_off(bandidx::win_row(band, n, pi0, pj0, item >> 3, item & 7));
-    const double* src = T + (item >> 3) * LDD + 6 * (item & 7);
-#pragma unroll
-    for (int h = 0; h < 3; ++h) st16_sc1(rs, o == WIN_OOB ? WIN_OOB : o + 16 * h, d2a_t{src[2 * h], src[2 * h + 1]});
-  }
-}
-// solved rows X (TRANSPOSED 6x6 blocks in memory): item = (pose ii, panel pose kk, column c): rows 6 ii .. 6 ii + 5 of
-// column 6 kk + c of the LDS tile (row-major, stride ULD)
-__device__ __forceinline__ void win_fetch_xtile(rsrc_t rs, int band, int k0, int pb, int i_last, int pose0, WinFetch& f) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int item = threadIdx.x + 256 * u;
-    const unsigned o = item < WIN_ITEMS ? win_off(bandidx::solved_item(band, k0, pb, i_last, pose0, item)) : WIN_OOB;
-#pragma unroll
-    for (int h = 0; h < 3; ++h) f.v[u][h] = ld16_sc1(rs, o == WIN_OOB ? WIN_OOB : o + 16 * h);
-  }
-}
-__device__ __forceinline__ void win_commit_xtile(const WinFetch& f, double* X) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int item = threadIdx.x + 256 * u;
-    if (item >= WIN_ITEMS) continue;
-    const int ii = item / (6 * PB), rem = item - 6 * PB * ii;
-    const int kk = rem / 6, c = rem - 6 * kk;
-    double* dst = X + (6 * ii) * ULD + 6 * kk + c;
-#pragma unroll
-    for (int h = 0; h < 3; ++h) {
-      dst[(2 * h) * ULD] = f.v[u][h].x;
-      dst[(2 * h + 1) * ULD] = f.v[u][h].y;
-    }
-  }
-}
-__device__ __forceinline__ void win_store_xtile(rsrc_t rs, int band, int k0, int pb, int i_last, int pose0, const double* X) {
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int item = threadIdx.x + 256 * u;
-    if (item >= WIN_ITEMS) continue;
-    const unsigned o = win_off(bandidx::solved_item(band, k0, pb, i_last, pose0, item));
-    const int ii = item / (6 * PB), rem = item - 6 * PB * ii;
-    const int kk = rem / 6, c = rem - 6 * kk;
-    const double* src = X + (6 * ii) * ULD + 6 * kk + c;
-#pragma unroll
-    for (int h = 0; h < 3; ++h) st16_sc1(rs, o == WIN_OOB ? WIN_OOB : o + 16 * h, d2a_t{src[(2 * h) * ULD], src[(2 * h + 1) * ULD]});
+  for (int u = 0; u < WIN_VPT; ++u) {
+    const double* src = T + (XT ? L.pk[u] >> 12 & 0xFFF : L.pk[u] & 0xFFF);
+    const bool mine = L.rel[u] != WIN_OOB;
+    st16_sc1(rs, win_vec_off(L, u, band, n, pi0, pj0), d2a_t{mine ? src[0] : 0.0, mine ? src[XT ? ULD : 1] : 0.0});
   }
 }
 
@@ -1937,33 +1921,17 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
   const size_t ystride = 6 * (size_t)n;
   const rsrc_t rsS = win_rsrc(B.Sb, 8 * bandidx::band_doubles(n, band));
   const rsrc_t rsP = win_rsrc(B.pub, 8ll * WIN_PUB * NE);
+  const WinLane WL = win_lane(band);
   {
     WinFetch f0;
-    win_fetch_tile(rsS, band, n, 0, 0, f0);
-    win_commit_tile(f0, sL);
+    win_fetch(rsS, WL, band, n, 0, 0, f0);
+    win_commit<false>(WL, f0, sL);
   }
   for (int e = tid; e < NB * n_rhs; e += 256) {
     const int q = e / NB, c = e - NB * q;
     s_rhs[e] = c < 6 * n ? ld_sc1(B.y + (size_t)q * ystride + c) : 0.0;
   }
   __syncthreads();
-  // Per-thread addresses of the three tiles every step touches -- sub-diagonal tile (I, I-1) and diagonal tile (I, I) by
-  // row segments, solved rows X of block row I -- computed ONCE for I = 1; they advance by win_step_stride per step
-  // (band_index.h; the CPU sweep checks that against win_row / solved_item).  What varies is the matrix's end only.
-  const unsigned step_bytes = (unsigned)(8 * bandidx::win_step_stride(band));
-  unsigned fa_off[2], fd_off[2], xs_off[2];
-  int f_ii[2], x_ii[2];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const int item = tid + 256 * u;
-    const bool in = item < WIN_ITEMS;
-    f_ii[u] = (item >> 3) / 6;
-    x_ii[u] = item / (6 * PB);
-    // as if the matrix had no end (n = INT_MAX): the end is tested per step
-    fa_off[u] = in ? win_off(bandidx::win_row(band, 0x7FFFFFFF, PB, 0, item >> 3, item & 7)) : WIN_OOB;
-    fd_off[u] = in ? win_off(bandidx::win_row(band, 0x7FFFFFFF, PB, PB, item >> 3, item & 7)) : WIN_OOB;
-    xs_off[u] = in ? win_off(bandidx::solved_item(band, 0, PB, 0x7FFFFFFF, PB, item)) : WIN_OOB;
-  }
   bool ok = true;
 #ifdef VUS_TIMING
   unsigned long long wt[10];
@@ -1977,7 +1945,8 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     VUS_WT(0);
     panel_factor<true, true>(B.Sb, n, band, k0, B.y, ystride, n_rhs, B.status, reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad,
                              sL, s_rhs, pb, sL, s_z);
-    lds_barrier();                 // the factor's stores to memory stay in flight
+    lds_barrier();
+    win_store<false>(rsS, WL, band, n, k0, k0, sL);      // the factor, on its way to memory
     VUS_WT(1);
     const int I = p + 1;
     const bool more = I < NT;
@@ -1993,17 +1962,8 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
         if (!s_go) { ok = false; break; }
       }
       VUS_WT(4);
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const bool inside = PB * I + f_ii[u] < n;             // the tile's rows past the matrix's end read as zero
-        const unsigned oa = (inside && fa_off[u] != WIN_OOB) ? fa_off[u] + step_bytes * (unsigned)p : WIN_OOB;
-        const unsigned od = (inside && fd_off[u] != WIN_OOB) ? fd_off[u] + step_bytes * (unsigned)p : WIN_OOB;
-#pragma unroll
-        for (int h = 0; h < 3; ++h) {
-          fa.v[u][h] = ld16_sc1(rsS, oa == WIN_OOB ? WIN_OOB : oa + 16 * h);
-          fb.v[u][h] = ld16_sc1(rsS, od == WIN_OOB ? WIN_OOB : od + 16 * h);
-        }
-      }
+      win_fetch(rsS, WL, band, n, PB * I, PB * p, fa);        // rows past the matrix's end read as zero
+      win_fetch(rsS, WL, band, n, PB * I, PB * I, fb);
 #pragma unroll
       for (int u = 0; u < 2; ++u) {       // NB * n_rhs <= 384 right-hand-side elements
         const int e = tid + 256 * u;
@@ -2032,8 +1992,8 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     if (tid == 0) __hip_atomic_store(F, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // panel p is out
     VUS_WT(3);
     if (!more) break;
-    win_commit_tile(fa, Xi);
-    win_commit_tile(fb, Xn);
+    win_commit<false>(WL, fa, Xi);
+    win_commit<false>(WL, fb, Xn);
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int e = tid + 256 * u;
@@ -2043,19 +2003,7 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     VUS_WT(5);
     solve_rows<true>(1, Xi, Xi, sL, sM);         // X of block row p+1
     VUS_WT(6);
-    // the solved rows, on their way to memory while the update below runs (same items as win_store_xtile)
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int item = tid + 256 * u;
-      if (item >= WIN_ITEMS) continue;
-      const bool inside = PB * I + x_ii[u] < n;
-      const unsigned o = (inside && xs_off[u] != WIN_OOB) ? xs_off[u] + step_bytes * (unsigned)p : WIN_OOB;
-      const int rem = item - 6 * PB * x_ii[u];
-      const int kk = rem / 6, c = rem - 6 * kk;
-      const double* src = Xi + (6 * x_ii[u]) * ULD + 6 * kk + c;
-#pragma unroll
-      for (int h = 0; h < 3; ++h) st16_sc1(rsS, o == WIN_OOB ? WIN_OOB : o + 16 * h, d2a_t{src[(2 * h) * ULD], src[(2 * h + 1) * ULD]});
-    }
+    win_store<true>(rsS, WL, band, n, PB * I, k0, Xi);      // the solved rows, on their way to memory while the update below runs
     {
       // next diagonal tile -= X X^T: its six lower MFMA tiles, at most two per wave; every element of Xn belongs to
       // one lane
@@ -2091,7 +2039,7 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     if (tid == 0) __hip_atomic_store(xflag + I, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     VUS_WT(8);
 #ifdef VUS_TIMING
-    if (tid == 0 && (p == 40 || p == 41) && NE > 60)
+    if (tid == 0 && p == 41 && NE > 60)
       printf("WT p=%d factor %llu wait %llu inv %llu publish %llu commit %llu solve %llu syrk %llu xflag %llu total %llu\n", p, wt[1] - wt[0],
              wt[4] - wt[1], wt[2] - wt[4], wt[3] - wt[2], wt[5] - wt[3], wt[6] - wt[5], wt[7] - wt[6], wt[8] - wt[7], wt[8] - wt[0]);
 #endif
@@ -2100,7 +2048,7 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     Xn = t_;
   }
   if (ok && NE < NT) {   // partial factorisation: the Schur complement's first diagonal tile and right-hand sides
-    win_store_tile(rsS, band, n, PB * NE, PB * NE, sL);
+    win_store<false>(rsS, WL, band, n, PB * NE, PB * NE, sL);
     for (int e = tid; e < NB * n_rhs; e += 256) {
       const int q = e / NB, c = e - NB * q;
       if (6 * PB * NE + c < 6 * n) st_sc1(B.y + (size_t)q * ystride + 6 * (size_t)PB * NE + c, s_rhs[e]);
@@ -2123,6 +2071,7 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
   const size_t ystride = 6 * (size_t)n;
   int hi, lo;
   bandidx::win_slot_pair(slot, hi, lo);
+  const WinLane WL = win_lane(band);
   double4_t acc[2][UQ];
 #pragma unroll
   for (int y2 = 0; y2 < 2; ++y2)
@@ -2160,7 +2109,7 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
             for (int r = 0; r < 4; ++r) Xi[(16 * a + kq + 4 * r) * LDD + 16 * b + arow] = -acc[sys][q][r];
           }
           __syncthreads();
-          win_store_tile(rsS, band, n, PB * I, PB * J, Xi);
+          win_store<false>(rsS, WL, band, n, PB * I, PB * J, Xi);
           if (d == 0)
             for (int e = tid; e < NB * n_rhs; e += 256) {
               const int q = e / NB, c = e - NB * q;
@@ -2171,7 +2120,6 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
       }
       const int k0 = PB * p;
       const int pb = min(PB, n - k0);
-      const int i_last = min(n - 1, k0 + pb - 1 + band);
       if (p == birth) {
         // birth: the tile's entries of the assembled system (nobody has written them in this launch)
 #pragma unroll
@@ -2220,7 +2168,7 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
         }
         __syncthreads();
         solve_rows(1, Xi, Xi, sL, sM);
-        win_store_xtile(rsS, band, k0, pb, i_last, PB * I, Xi);
+        win_store<true>(rsS, WL, band, n, PB * I, k0, Xi);
         cb_drain();
         __syncthreads();
         if (tid == 0) __hip_atomic_store(xflag + I, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2232,10 +2180,10 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
       if (!s_go) { live = false; continue; }
       {
         WinFetch fi, fj;
-        win_fetch_xtile(rsS, band, k0, pb, i_last, PB * I, fi);
-        if (d > 0) win_fetch_xtile(rsS, band, k0, pb, i_last, PB * J, fj);
-        win_commit_xtile(fi, Xi);
-        if (d > 0) win_commit_xtile(fj, Xj);
+        win_fetch(rsS, WL, band, n, PB * I, k0, fi);
+        if (d > 0) win_fetch(rsS, WL, band, n, PB * J, k0, fj);
+        win_commit<true>(WL, fi, Xi);
+        if (d > 0) win_commit<true>(WL, fj, Xj);
       }
       if (d == 0)
         for (int e = tid; e < NB * n_rhs; e += 256) {
@@ -2264,7 +2212,7 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
           for (int r = 0; r < 4; ++r) Xi[(16 * a + kq + 4 * r) * LDD + 16 * b + arow] = -acc[sys][q][r];
         }
         __syncthreads();
-        win_store_tile(rsS, band, n, PB * I, PB * J, Xi);
+        win_store<false>(rsS, WL, band, n, PB * I, PB * J, Xi);
         __syncthreads();             // yown is complete
         if (d == 0)
           for (int e = tid; e < NB * n_rhs; e += 256) {

@@ -27,9 +27,13 @@ VUS_HD long long band_doubles(int n, int band) { return 36ll * n * (band + 1); }
 VUS_HD long long blk(int band, int i, int k) { return 36ll * ((long long)i * (band + 1) + (i - k)); }
 
 // ---- panel_factor: lane R = scalar row of the panel, kb = 6-column block; 6 contiguous doubles --------------------
+VUS_HD bool panel_row_ok(int band, int nb, int R, int kb) {
+  const int ii = R / 6;
+  return R < nb && kb <= ii && ii - kb <= band;
+}
 VUS_HD long long panel_row(int band, int k0, int nb, int R, int kb) {
   const int ii = R / 6, rr = R - 6 * ii;
-  if (!(R < nb && kb <= ii && ii - kb <= band)) return -1;
+  if (!panel_row_ok(band, nb, R, kb)) return -1;
   return blk(band, k0 + ii, k0 + kb) + 6 * rr;
 }
 
@@ -89,20 +93,36 @@ VUS_HD long long win_scalar(int band, int n, int pi0, int pj0, int Rr, int Cc) {
   return ok ? blk(band, i, j) + 6 * rm + cm : -1;
 }
 
-// the same tile by ROW SEGMENTS: item = (scalar row Rr, block column kk) -> the 6 contiguous doubles of that row inside
-// block (pi0 + Rr / 6, pj0 + kk), or -1 if the band does not store the block.  (On a diagonal block the segment includes
-// the block's upper triangle, which nobody reads: the factor kernels use lower triangles only.)
-VUS_HD long long win_row(int band, int n, int pi0, int pj0, int Rr, int kk) {
-  const int i = pi0 + Rr / 6, rm = Rr % 6;
-  const int j = pj0 + kk;
-  const bool ok = i < n && j <= i && i - j <= band;
-  return ok ? blk(band, i, j) + 6 * rm : -1;
+// the same tile in ADDRESS ORDER: pose row i of the tile is the 2304 contiguous bytes of the blocks (i, pj0 + 7 .. pj0),
+// 144 vectors of 16 bytes; vector v = 144 ii + w holds the elements e, e + 1 (e = 2 (w mod 18)) of block
+// (pi0 + ii, pj0 + 7 - w / 18).  This is how chol_window_kernel moves tiles: consecutive lanes, consecutive 16 bytes.
+// A block of SOLVED rows (stored transposed) has the same addresses: vector v of the rows pose0.. against the panel at
+// k0 is win_vec(band, n, pose0, k0, v), its elements e, e + 1 being (column e / 6, rows e % 6, e % 6 + 1) of the block.
+constexpr int WIN_VECS = 8 * 144;
+VUS_HD void win_vec_pos(int v, int& ii, int& kk, int& e) {
+  ii = v / 144;
+  const int w = v - 144 * ii, o = w / 18;
+  kk = 7 - o;
+  e = 2 * (w - 18 * o);
 }
-
-// A tile that moves down the diagonal by one tile (8 poses) keeps every (row-in-tile, block-column distance) and all of
-// its addresses advance by this many doubles: the critical workgroup of chol_window_kernel computes its per-thread
-// offsets ONCE and adds win_step_stride per panel step (checked against win_row / solved_item by the CPU sweep).
-VUS_HD long long win_step_stride(int band) { return 36ll * PB * (band + 1); }
+VUS_HD long long win_vec(int band, int n, int pi0, int pj0, int v) {
+  int ii, kk, e;
+  win_vec_pos(v, ii, kk, e);
+  const int i = pi0 + ii, j = pj0 + kk;
+  const bool ok = v < WIN_VECS && i < n && j <= i && i - j <= band;
+  return ok ? blk(band, i, j) + e : -1;
+}
+// The form the kernel computes: win_vec = win_vec_base(tile) + win_vec_rel(thread's vector), valid iff win_vec_ok; the
+// thread keeps rel, ii and dk = kk - ii for the whole launch (checked against win_vec by the CPU sweep).
+VUS_HD long long win_vec_base(int band, int pi0, int pj0) { return 36ll * ((long long)pi0 * (band + 1) + (pi0 - pj0 - 7)); }
+VUS_HD long long win_vec_rel(int band, int v) {
+  const int ii = v / 144;
+  return 36ll * ii * (band + 2) + 2 * (v - 144 * ii);
+}
+VUS_HD bool win_vec_ok(int band, int n, int pi0, int pj0, int ii, int dk) {
+  const int dd = pi0 - pj0;
+  return pi0 + ii < n && dk <= dd && -dk <= band - dd;     // i < n, j <= i, i - j <= band
+}
 
 // ---- chol_window: which tile a window slot hosts at panel step p ----------------------------------------------------
 // Tiles are 8 x 8 poses; tile (I, J), J <= I <= J + D, is LIVE during the panel steps [I - D, J] (its first update to its
