@@ -1,0 +1,30 @@
+"""Cycle marks of one panel step of chol_window_kernel's critical workgroup (a -DVUS_TIMING build of the library, given by
+VUS_HIP_LIB): where the 17 us of a step go.  usage: VUS_HIP_LIB=.../libvus_t_X.so python tools/win_timing.py"""
+import ctypes, json, sys
+sys.path.insert(0, __file__.rsplit("/", 2)[0])
+import numpy as np
+import torch
+from visual_underwater_slam_amd import synth, _lib, ba_bench
+from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
+
+n_kf = 2000
+s = synth.ba_sequence(n_kf, 25 * n_kf, 1000)
+nL = len(s["points_gt"])
+prob = StereoBAProblem(s["obs_pose"], s["obs_point"], s["meas"], n_kf, nL, s["K"], s["sigma"], prior_pose=[0],
+                       prior_T=s["poses_gt"][:1], prior_sigmas=s["prior_sigmas"][None])
+sv = StereoBASolver(prob)
+p0, x0 = torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda()
+_lib.call("vus_ba_set_tuning", _lib.TUNE_BAND_MODE, 3)
+lib = _lib.load()
+names = ["factor_in", "factor_loop", "factor_out", "factor_store", "hand_wait", "fetch+inverses", "publish", "commit", "solve", "syrk", "xflag"]
+rows = []
+for it in range(4):
+    sv.optimize(p0, x0)
+    torch.cuda.synchronize()
+    buf = (ctypes.c_ulonglong * 16)()
+    assert lib.vus_debug_read_wtm(buf) == 0
+    t = np.array(list(buf), dtype=np.int64)
+    rows.append(np.diff(t[:12]))
+rows = np.array(rows)
+med = np.median(rows, axis=0).astype(int)
+print(json.dumps({"cycles": dict(zip(names, med.tolist())), "total": int(med.sum()), "stage_ms": ba_bench.stage_breakdown(sv, p0, x0)}))

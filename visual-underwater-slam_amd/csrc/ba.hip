@@ -690,6 +690,13 @@ __device__ __forceinline__ const double* blk_ptr(const double* Sb, int band, int
   return Sb + 36 * ((size_t)i * (band + 1) + (i - k));
 }
 
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {      // v of the lane the DPP control selects
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ double bcast_lane(double v, int src_lane) {   // src_lane wave-uniform
   const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
   const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
@@ -729,27 +736,30 @@ __device__ __forceinline__ void panel_update(double (&blk)[6], const double (&xr
   }
 }
 
+// -DVUS_TIMING: s_memtime marks of ONE panel step of the window kernel's critical workgroup (system 0, panel 41), kept in
+// a device array and printed once after the last step, so that the marks cost thread 0 a scalar load and a store and
+// nothing else (a printf inside the loop costs the whole kernel registers and shifts every number)
 #ifdef VUS_TIMING
-#define VUS_PT(n) const unsigned long long pt##n = __builtin_amdgcn_s_memtime()
-#define VUS_PP() printf("PF in %llu bar %llu loop %llu bar %llu out %llu\n", pt0 - pt8, pt1 - pt0, pt2 - pt1, pt3 - pt2, pt9 - pt3)
+__device__ unsigned long long g_wtm[16];
+__shared__ unsigned long long s_wtm[16];       // marks go to LDS (a global store per mark would stall thread 0's wave at the next reuse of its registers)
+#define VUS_WM(k) do { if (vus_wm_on && threadIdx.x == 0) s_wtm[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
-#define VUS_PT(n)
-#define VUS_PP()
+#define VUS_WM(k)
 #endif
 // FROM_LDS: the 48x48 block (row stride LDD) and the right-hand-side rows (row stride NB) are handed over in
 // LDS by the workgroup that has just produced them (fused launch) instead of being re-read from memory;
 // only the first lds_poses poses of the panel were touched by that update (bands narrower than a panel),
 // the rest still comes from memory.
-// PUBLISH (persistent window kernel): the factor and the solved right-hand sides leave the workgroup with agent-scope
-// (sc1) stores, because workgroups of the SAME launch read them; lds_out / lds_rhs_out also receive the factor (row
-// stride LDD, zeros above the diagonal) and the solved right-hand-side rows (row stride NB) for the caller's next phase.
+// PUBLISH (persistent window kernel): nothing is written to memory here; lds_out / lds_rhs_out receive the factor (row
+// stride LDD, zeros above the diagonal) and the solved right-hand-side rows (row stride NB), and the caller stores both
+// with agent-scope (sc1) stores, because workgroups of the SAME launch read them.
 template <bool FROM_LDS, bool PUBLISH = false>
 __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, int k0, double* yv, size_t ystride,
                                              int n_rhs, int* __restrict__ status, double (*s_x)[64 * 6],
                                              int& s_bad, const double* lds_tile = nullptr,
                                              const double* lds_rhs = nullptr, int lds_poses = 0,
                                              double* lds_out = nullptr, double* lds_rhs_out = nullptr) {
-  VUS_PT(8);
+  [[maybe_unused]] const bool vus_wm_on = PUBLISH && k0 == 8 * 41 && blockIdx.x == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
@@ -776,9 +786,8 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
       for (int c = 0; c < 6; ++c) row[j][c] = src[c];
     }
   }
-  VUS_PT(0);
   __syncthreads();
-  VUS_PT(1);
+  VUS_WM(1);
 #pragma unroll
   for (int s = 0; s < PB; ++s) {
     if (s < pb) {   // uniform
@@ -840,9 +849,8 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
       }
     }
   }
-  VUS_PT(2);
+  VUS_WM(2);
   __syncthreads();
-  VUS_PT(3);
   if (threadIdx.x == 0 && s_bad != 0x7FFFFFFF && status[0] == 0) status[0] = s_bad;
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -857,20 +865,16 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
 #pragma unroll
       for (int c = 0; c < 6; ++c) lds_out[R * LDD + 6 * kb + c] = (stored && 6 * kb + c <= R) ? row[j][c] : 0.0;
     }
-    if (is_rhs && kb < pb) {
-#pragma unroll
-      for (int c = 0; c < 6; ++c) {
-        if (PUBLISH) __hip_atomic_store(yrow + 6 * kb + c, row[j][c], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else yrow[6 * kb + c] = row[j][c];
-      }
+    if (!PUBLISH && is_rhs && kb < pb) {     // PUBLISH: the caller stores them from lds_rhs_out (a store from `row` here
+#pragma unroll                             // would hold the registers the LDS copies below rewrite: a store round trip each)
+      for (int c = 0; c < 6; ++c) yrow[6 * kb + c] = row[j][c];
     }
     if (PUBLISH && lds_rhs_out != nullptr && R >= nb && R < nb + n_rhs) {
 #pragma unroll
       for (int c = 0; c < 6; ++c) lds_rhs_out[(R - nb) * NB + 6 * kb + c] = kb < pb ? row[j][c] : 0.0;
     }
   }
-  VUS_PT(9);
-  if (PUBLISH && threadIdx.x == 0 && k0 == 320) VUS_PP();
+  VUS_WM(3);
 }
 
 // One block-band system handed to the factorisation kernels: storage, right-hand sides [n_rhs, 6 n] (solved in
@@ -945,13 +949,23 @@ __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* 
   if (tid < NB) {   // column n of the inverse of 8x8 diagonal block h by forward substitution (rows past nb: identity)
     const int h = tid >> 3, n = tid & 7;
     const double* Ld = sL + (8 * h) * LDD + 8 * h;
+    // every LDS operand requested before the first use (the compiler would otherwise wait for each in turn: 14 dependent
+    // LDS round trips on the critical workgroup's chain)
+    double l[8][8], iv[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      iv[r] = sInv[8 * h + r];
+#pragma unroll
+      for (int k = 0; k < r; ++k) l[r][k] = Ld[r * LDD + k];
+    }
+    __builtin_amdgcn_sched_barrier(0);
     double m[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       double acc = (r == n) ? 1.0 : 0.0;
 #pragma unroll
-      for (int k = 0; k < r; ++k) acc -= Ld[r * LDD + k] * m[k];
-      m[r] = acc * sInv[8 * h + r];
+      for (int k = 0; k < r; ++k) acc -= l[r][k] * m[k];
+      m[r] = acc * iv[r];
     }
     double* Mq = sM + 16 * MLD * (h >> 1) + (8 * MLD + 8) * (h & 1);
 #pragma unroll
@@ -969,15 +983,28 @@ __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* 
     double t = 0.0;
     if (act) {   // T = C A^-1
       const double* Lc = sL + (16 * b3 + 8 + r) * LDD + 16 * b3;
+      double lc[8], ma[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t += Lc[k] * Mb[MLD * k + cq];
+      for (int k = 0; k < 8; ++k) {
+        lc[k] = Lc[k];
+        ma[k] = Mb[MLD * k + cq];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t += lc[k] * ma[k];
       Mb[MLD * (8 + r) + cq] = t;     // parked in the quadrant it will leave
     }
     wg_barrier<LDS_ONLY>();
     if (act) {   // -B^-1 T
-      double u = 0.0;
+      double u = 0.0, mb[8], tk[8];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) u -= Mb[MLD * (8 + r) + 8 + k] * Mb[MLD * (8 + k) + cq];
+      for (int k = 0; k < 8; ++k) {
+        mb[k] = Mb[MLD * (8 + r) + 8 + k];
+        tk[k] = Mb[MLD * (8 + k) + cq];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) u -= mb[k] * tk[k];
       t = u;
     }
     wg_barrier<LDS_ONLY>();
@@ -996,6 +1023,7 @@ __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* 
       av[s2] = pm[4 * s2];
       bv[s2] = pl[4 * s2 * LDD];
     }
+    __builtin_amdgcn_sched_barrier(0);
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int s2 = 0; s2 < 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
@@ -1037,6 +1065,7 @@ __device__ __forceinline__ void solve_rows(int n_tiles, double* __restrict__ Xa,
         av0[s2] = pa0[4 * s2];
         av1[s2] = two ? pa1[4 * s2] : 0.0;
       }
+      __builtin_amdgcn_sched_barrier(0);
       double4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int s2 = 0; s2 < 12; ++s2) {
@@ -1933,23 +1962,26 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
   }
   __syncthreads();
   bool ok = true;
-#ifdef VUS_TIMING
-  unsigned long long wt[10];
-#define VUS_WT(k) wt[k] = __builtin_amdgcn_s_memtime()
-#else
-#define VUS_WT(k)
-#endif
   for (int p = 0; p < NE; ++p) {
     const int k0 = PB * p;
     const int pb = min(PB, n - k0), nb = 6 * pb;
-    VUS_WT(0);
+    [[maybe_unused]] const bool vus_wm_on = p == 41 && blockIdx.x == 0;
+    VUS_WM(0);
     panel_factor<true, true>(B.Sb, n, band, k0, B.y, ystride, n_rhs, B.status, reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad,
                              sL, s_rhs, pb, sL, s_z);
-    lds_barrier();
-    win_store<false>(rsS, WL, band, n, k0, k0, sL);      // the factor, on its way to memory
-    VUS_WT(1);
     const int I = p + 1;
     const bool more = I < NT;
+    // the hand-over flag of block row I is read NOW and looked at after the stores below: the round trip of the usual
+    // case (handed over long ago) is hidden
+    int hand_seen = 0;
+    if (more && I >= 2 && tid == 0) hand_seen = __hip_atomic_load(hand + I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    lds_barrier();
+    win_store<false>(rsS, WL, band, n, k0, k0, sL);      // the factor and the solved right-hand sides, on their way to memory
+    for (int e = tid; e < NB * n_rhs; e += 256) {
+      const int q = e / NB, c = e - NB * q;
+      if (c < nb) st_sc1(B.y + (size_t)q * ystride + 6 * (size_t)k0 + c, s_z[e]);
+    }
+    VUS_WM(4);
     // The next block row's two right-most tiles carry every update before step p; their owners handed them over while
     // this panel was being factored.  Their loads are issued NOW and land while the inverse blocks are computed.
     WinFetch fa, fb;
@@ -1957,11 +1989,11 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     bool okr[2];
     if (more) {
       if (I >= 2) {
-        if (tid == 0) s_go = cb_wait(hand + I, 2, abort_flag);
+        if (tid == 0) s_go = hand_seen >= 2 || cb_wait(hand + I, 2, abort_flag);
         lds_barrier();
         if (!s_go) { ok = false; break; }
       }
-      VUS_WT(4);
+      VUS_WM(5);
       win_fetch(rsS, WL, band, n, PB * I, PB * p, fa);        // rows past the matrix's end read as zero
       win_fetch(rsS, WL, band, n, PB * I, PB * I, fb);
 #pragma unroll
@@ -1975,7 +2007,7 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     if (tid < NB) sInv[tid] = tid < nb ? 1.0 / sL[tid * LDD + tid] : 1.0;
     lds_barrier();
     block_inverses<true>(sL, sM, sInv);
-    VUS_WT(2);
+    VUS_WM(6);
     {
       // the six 16 x 16 blocks G(1,0), G(2,0), G(2,1), M_0, M_1, M_2, row-major: 768 pairs of doubles, 3 per thread
 #pragma unroll
@@ -1987,22 +2019,23 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
         st16_sc1(rsP, (unsigned)(8 * ((size_t)p * WIN_PUB) + 16 * e2), d2a_t{src[0], src[1]});
       }
     }
-    cb_drain();                    // the factor, the solved right-hand sides, the inverse blocks are in memory (and the
-    __syncthreads();               // tile loads above have landed)
-    if (tid == 0) __hip_atomic_store(F, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // panel p is out
-    VUS_WT(3);
-    if (!more) break;
-    win_commit<false>(WL, fa, Xi);
-    win_commit<false>(WL, fb, Xn);
+    VUS_WM(7);
+    if (more) {                    // the next block row's tiles go to LDS while the stores above travel
+      win_commit<false>(WL, fa, Xi);
+      win_commit<false>(WL, fb, Xn);
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int e = tid + 256 * u;
-      if (e < NB * n_rhs) s_rhs[e] = okr[u] ? vr[u] : 0.0;
+      for (int u = 0; u < 2; ++u) {
+        const int e = tid + 256 * u;
+        if (e < NB * n_rhs) s_rhs[e] = okr[u] ? vr[u] : 0.0;
+      }
     }
-    lds_barrier();
-    VUS_WT(5);
+    cb_drain();                    // the factor, the solved right-hand sides, the inverse blocks are in memory
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(F, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // panel p is out
+    VUS_WM(8);
+    if (!more) break;
     solve_rows<true>(1, Xi, Xi, sL, sM);         // X of block row p+1
-    VUS_WT(6);
+    VUS_WM(9);
     win_store<true>(rsS, WL, band, n, PB * I, k0, Xi);      // the solved rows, on their way to memory while the update below runs
     {
       // next diagonal tile -= X X^T: its six lower MFMA tiles, at most two per wave; every element of Xn belongs to
@@ -2018,30 +2051,50 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
         for (int r = 0; r < 4; ++r) acc[r] = -Xn[(16 * a + kq + 4 * r) * LDD + 16 * b + arow];
         const double* pa = Xi + (16 * a + arow) * ULD + kq;
         const double* pbm = Xi + (16 * b + arow) * ULD + kq;
+        double av[NB / 4], bv[NB / 4];
 #pragma unroll
-        for (int s2 = 0; s2 < NB / 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * s2], pbm[4 * s2], acc, 0, 0, 0);
+        for (int s2 = 0; s2 < NB / 4; ++s2) {
+          av[s2] = pa[4 * s2];
+          bv[s2] = pbm[4 * s2];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < NB / 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) Xn[(16 * a + kq + 4 * r) * LDD + 16 * b + arow] = -acc[r];
       }
-      // its right-hand sides -= X z (the waves with one MFMA tile take them)
-      if (wave >= 2)
-        for (int e = tid - 128; e < NB * n_rhs; e += 128) {
-          const int q = e / NB, r = e - NB * q;
+      // its right-hand sides -= X z (the waves with one MFMA tile take them): eight lanes per element, six columns
+      // each, summed across the lanes with DPP moves
+      if (wave >= 2) {
+        const int idx = tid - 128, part = idx & 7;
+        for (int e0 = 0; e0 < NB * n_rhs; e0 += 16) {
+          const int e = e0 + (idx >> 3);
+          const bool on = e < NB * n_rhs;
+          const int q = on ? e / NB : 0, r = on ? e - NB * q : 0;
+          double xv[6], zv[6];
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            xv[k] = Xi[r * ULD + 6 * part + k];
+            zv[k] = s_z[q * NB + 6 * part + k];
+          }
+          __builtin_amdgcn_sched_barrier(0);
           double sum = 0.0;
-#pragma unroll 8
-          for (int c = 0; c < NB; ++c) sum += Xi[r * ULD + c] * s_z[q * NB + c];
-          s_rhs[e] -= sum;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) sum += xv[k] * zv[k];
+          sum += dpp_f64<0xB1>(sum);      // quad_perm [1, 0, 3, 2]
+          sum += dpp_f64<0x4E>(sum);      // quad_perm [2, 3, 0, 1]
+          sum += dpp_f64<0x141>(sum);     // row_half_mirror: the other quad of the eight
+          if (on && part == 0) s_rhs[e] -= sum;
         }
+      }
     }
-    VUS_WT(7);
+    VUS_WM(10);
     cb_drain();
     __syncthreads();
     if (tid == 0) __hip_atomic_store(xflag + I, p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    VUS_WT(8);
+    VUS_WM(11);
 #ifdef VUS_TIMING
-    if (tid == 0 && p == 41 && NE > 60)
-      printf("WT p=%d factor %llu wait %llu inv %llu publish %llu commit %llu solve %llu syrk %llu xflag %llu total %llu\n", p, wt[1] - wt[0],
-             wt[4] - wt[1], wt[2] - wt[4], wt[3] - wt[2], wt[5] - wt[3], wt[6] - wt[5], wt[7] - wt[6], wt[8] - wt[7], wt[8] - wt[0]);
+    if (vus_wm_on && tid < 12) g_wtm[tid] = s_wtm[tid];
 #endif
     double* t_ = sL;
     sL = Xn;
@@ -3061,3 +3114,10 @@ extern "C" int vus_ba_eval_step(const vus_ba_problem* P, const double* poses, co
   VUS_CHECK_LAUNCH("ba_eval_step");
   return VUS_OK;
 }
+
+#ifdef VUS_TIMING
+// timing builds only (tools/win_timing.py): the s_memtime marks of the window kernel's critical workgroup, panel 41
+extern "C" int vus_debug_read_wtm(unsigned long long* out16) {
+  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wtm), sizeof(g_wtm)) == hipSuccess ? 0 : -1;
+}
+#endif
