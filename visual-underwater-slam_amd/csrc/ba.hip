@@ -752,13 +752,15 @@ __shared__ unsigned long long s_wtm[16];       // marks go to LDS (a global stor
 // the rest still comes from memory.
 // PUBLISH (persistent window kernel): nothing is written to memory here; lds_out / lds_rhs_out receive the factor (row
 // stride LDD, zeros above the diagonal) and the solved right-hand-side rows (row stride NB), and the caller stores both
-// with agent-scope (sc1) stores, because workgroups of the SAME launch read them.
+// with agent-scope (sc1) stores, because workgroups of the SAME launch read them; lds_inv receives 1 / L_cc of the
+// panel's 6 pb columns.
 template <bool FROM_LDS, bool PUBLISH = false>
 __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, int k0, double* yv, size_t ystride,
                                              int n_rhs, int* __restrict__ status, double (*s_x)[64 * 6],
                                              int& s_bad, const double* lds_tile = nullptr,
                                              const double* lds_rhs = nullptr, int lds_poses = 0,
-                                             double* lds_out = nullptr, double* lds_rhs_out = nullptr) {
+                                             double* lds_out = nullptr, double* lds_rhs_out = nullptr,
+                                             double* lds_inv = nullptr) {
   [[maybe_unused]] const bool vus_wm_on = PUBLISH && k0 == 8 * 41 && blockIdx.x == 0;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int pb = min(PB, n_poses - k0);
@@ -830,6 +832,10 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) s_x[s % 3][6 * lane + k] = a[k];
+        if (PUBLISH && lds_inv != nullptr && lane == 0) {      // 1 / L_cc, for the caller's inverse blocks
+#pragma unroll
+          for (int c = 0; c < 6; ++c) lds_inv[6 * s + c] = inv[c];
+        }
       }
       __syncthreads();
       // the step s-1 update of the owner's other block was deferred behind the factorisation and the
@@ -1879,7 +1885,7 @@ __device__ __forceinline__ WinLane win_lane(int band) {
     const unsigned nat = (unsigned)((6 * ii + e / 6) * LDD + 6 * kk + e % 6);       // elements (r, c), (r, c + 1)
     const unsigned xt = (unsigned)((6 * ii + e % 6) * ULD + 6 * kk + e / 6);        // elements (r, c), (r + 1, c): transposed blocks
     L.rel[u] = v < bandidx::WIN_VECS ? (unsigned)(8 * bandidx::win_vec_rel(band, v)) : WIN_OOB;
-    L.pk[u] = nat | xt << 12 | (unsigned)ii << 24 | (unsigned)(kk - ii + 8) << 27;
+    L.pk[u] = v < bandidx::WIN_VECS ? nat | xt << 12 | (unsigned)ii << 24 | (unsigned)(kk - ii + 8) << 27 : 8u << 27;
   }
   return L;
 }
@@ -1905,13 +1911,21 @@ __device__ __forceinline__ void win_commit(const WinLane& L, const WinFetch& f, 
     dst[XT ? ULD : 1] = f.v[u].y;
   }
 }
-template <bool XT>
+// EAGER (the critical workgroup): all LDS reads requested before the first store waits for its own; the window slots,
+// which keep two tiles in accumulators, have no registers to spare for that.
+template <bool XT, bool EAGER = false>
 __device__ __forceinline__ void win_store(rsrc_t rs, const WinLane& L, int band, int n, int pi0, int pj0, const double* T) {
+  d2a_t v[WIN_VPT];
 #pragma unroll
-  for (int u = 0; u < WIN_VPT; ++u) {
+  for (int u = 0; u < WIN_VPT; ++u) {      // a thread without a fifth vector reads element 0 (its store is dropped)
     const double* src = T + (XT ? L.pk[u] >> 12 & 0xFFF : L.pk[u] & 0xFFF);
-    const bool mine = L.rel[u] != WIN_OOB;
-    st16_sc1(rs, win_vec_off(L, u, band, n, pi0, pj0), d2a_t{mine ? src[0] : 0.0, mine ? src[XT ? ULD : 1] : 0.0});
+    v[u] = d2a_t{src[0], src[XT ? ULD : 1]};
+    if (!EAGER) st16_sc1(rs, win_vec_off(L, u, band, n, pi0, pj0), v[u]);
+  }
+  if (EAGER) {
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < WIN_VPT; ++u) st16_sc1(rs, win_vec_off(L, u, band, n, pi0, pj0), v[u]);
   }
 }
 
@@ -1968,7 +1982,7 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     [[maybe_unused]] const bool vus_wm_on = p == 41 && blockIdx.x == 0;
     VUS_WM(0);
     panel_factor<true, true>(B.Sb, n, band, k0, B.y, ystride, n_rhs, B.status, reinterpret_cast<double(*)[64 * 6]>(Xi), s_bad,
-                             sL, s_rhs, pb, sL, s_z);
+                             sL, s_rhs, pb, sL, s_z, sInv);
     const int I = p + 1;
     const bool more = I < NT;
     // the hand-over flag of block row I is read NOW and looked at after the stores below: the round trip of the usual
@@ -1976,7 +1990,7 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     int hand_seen = 0;
     if (more && I >= 2 && tid == 0) hand_seen = __hip_atomic_load(hand + I, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     lds_barrier();
-    win_store<false>(rsS, WL, band, n, k0, k0, sL);      // the factor and the solved right-hand sides, on their way to memory
+    win_store<false, true>(rsS, WL, band, n, k0, k0, sL);      // the factor and the solved right-hand sides, on their way to memory
     for (int e = tid; e < NB * n_rhs; e += 256) {
       const int q = e / NB, c = e - NB * q;
       if (c < nb) st_sc1(B.y + (size_t)q * ystride + 6 * (size_t)k0 + c, s_z[e]);
@@ -2004,8 +2018,10 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
         vr[u] = ld_sc1(B.y + (okr[u] ? (size_t)q * ystride + 6 * (size_t)PB * I + c : 0));
       }
     }
-    if (tid < NB) sInv[tid] = tid < nb ? 1.0 / sL[tid * LDD + tid] : 1.0;
-    lds_barrier();
+    if (nb < NB) {                 // the matrix's last panel: identity past its end (sInv[0 .. nb) came from panel_factor)
+      if (tid >= nb && tid < NB) sInv[tid] = 1.0;
+      lds_barrier();
+    }
     block_inverses<true>(sL, sM, sInv);
     VUS_WM(6);
     {
@@ -2036,32 +2052,47 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     if (!more) break;
     solve_rows<true>(1, Xi, Xi, sL, sM);         // X of block row p+1
     VUS_WM(9);
-    win_store<true>(rsS, WL, band, n, PB * I, k0, Xi);      // the solved rows, on their way to memory while the update below runs
+    win_store<true, true>(rsS, WL, band, n, PB * I, k0, Xi);      // the solved rows, on their way to memory while the update below runs
     {
       // next diagonal tile -= X X^T: its six lower MFMA tiles, at most two per wave; every element of Xn belongs to
       // one lane
+      {
+        // tile index t = 3 a + b: wave 0 -> (0,0), (2,1); wave 1 -> (1,0), (2,2); wave 2 -> (1,1); wave 3 -> (2,0).  The
+        // two tiles of a wave are loaded together and their (independent) MFMA chains issued alternately.
+        const int t0 = wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 4 : 6, t1 = wave == 0 ? 7 : 8;
+        const bool two = wave < 2;
+        const int a0 = t0 / UMT, b0 = t0 - UMT * a0, a1 = t1 / UMT, b1 = t1 - UMT * a1;
+        double4_t acc0, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        // tile index t = 3 a + b: wave 0 -> (0,0), (2,1); wave 1 -> (1,0), (2,2); wave 2 -> (1,1); wave 3 -> (2,0)
-        const int t = q == 0 ? (wave == 0 ? 0 : wave == 1 ? 3 : wave == 2 ? 4 : 6) : (wave == 0 ? 7 : wave == 1 ? 8 : -1);
-        if (t < 0) continue;
-        const int a = t / UMT, b = t - UMT * a;
-        double4_t acc;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc[r] = -Xn[(16 * a + kq + 4 * r) * LDD + 16 * b + arow];
-        const double* pa = Xi + (16 * a + arow) * ULD + kq;
-        const double* pbm = Xi + (16 * b + arow) * ULD + kq;
-        double av[NB / 4], bv[NB / 4];
-#pragma unroll
-        for (int s2 = 0; s2 < NB / 4; ++s2) {
-          av[s2] = pa[4 * s2];
-          bv[s2] = pbm[4 * s2];
+        for (int r = 0; r < 4; ++r) {
+          acc0[r] = -Xn[(16 * a0 + kq + 4 * r) * LDD + 16 * b0 + arow];
+          if (two) acc1[r] = -Xn[(16 * a1 + kq + 4 * r) * LDD + 16 * b1 + arow];
         }
-        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int s2 = 0; s2 < NB / 4; ++s2) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[s2], bv[s2], acc, 0, 0, 0);
+        for (int h = 0; h < 2; ++h) {      // two halves of the 48 columns: the operands of one half fit the registers left
+          constexpr int HS = NB / 8;
+          double av0[HS], bv0[HS], av1[HS], bv1[HS];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) Xn[(16 * a + kq + 4 * r) * LDD + 16 * b + arow] = -acc[r];
+          for (int s2 = 0; s2 < HS; ++s2) {
+            const int c = kq + 4 * (HS * h + s2);
+            av0[s2] = Xi[(16 * a0 + arow) * ULD + c];
+            bv0[s2] = Xi[(16 * b0 + arow) * ULD + c];
+            av1[s2] = two ? Xi[(16 * a1 + arow) * ULD + c] : 0.0;
+            bv1[s2] = two ? Xi[(16 * b1 + arow) * ULD + c] : 0.0;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int s2 = 0; s2 < HS; ++s2) {
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av0[s2], bv0[s2], acc0, 0, 0, 0);
+            if (two) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av1[s2], bv1[s2], acc1, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          Xn[(16 * a0 + kq + 4 * r) * LDD + 16 * b0 + arow] = -acc0[r];
+          if (two) Xn[(16 * a1 + kq + 4 * r) * LDD + 16 * b1 + arow] = -acc1[r];
+        }
       }
       // its right-hand sides -= X z (the waves with one MFMA tile take them): eight lanes per element, six columns
       // each, summed across the lanes with DPP moves
