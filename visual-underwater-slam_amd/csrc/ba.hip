@@ -806,13 +806,14 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
         for (int r = 0; r < 6; ++r)
 #pragma unroll
           for (int c = 0; c <= r; ++c) D[r][c] = bcast_lane(a[c], 6 * s + r);
+        // A non-positive pivot is NOTED (first one of the block) and reported after the block; the arithmetic goes on
+        // with it (NaN from there on: the caller discards a solve whose status is set).  Testing every pivot before
+        // its square root put a compare, two selects and a branch into each of the 48 links of the panel's chain.
+        int first_bad = 6;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-          double d = D[c][c];
-          if (!(d > 0.0)) {
-            if (lane == 0) atomicMin(&s_bad, 6 * k0 + 6 * s + c + 1);
-            d = 1.0;
-          }
+          const double d = D[c][c];
+          if (!(d > 0.0) && first_bad == 6) first_bad = c;
           const double rs = rsqrt_newton(d);
           inv[c] = rs;
 #pragma unroll
@@ -832,6 +833,7 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
         }
 #pragma unroll
         for (int k = 0; k < 6; ++k) s_x[s % 3][6 * lane + k] = a[k];
+        if (first_bad < 6 && lane == 0) atomicMin(&s_bad, 6 * k0 + 6 * s + first_bad + 1);
         if (PUBLISH && lds_inv != nullptr && lane == 0) {      // 1 / L_cc, for the caller's inverse blocks
 #pragma unroll
           for (int c = 0; c < 6; ++c) lds_inv[6 * s + c] = inv[c];
