@@ -732,7 +732,7 @@ __device__ __forceinline__ void panel_update(double (&blk)[6], const double (&xr
     for (int k = 0; k < 6; ++k)
 #pragma unroll
       for (int c = 0; c < 3; ++c) blk[3 * h + c] = __builtin_fma(-xr[k], w[6 * c + k], blk[3 * h + c]);
-    __builtin_amdgcn_sched_barrier(0);
+    if (h == 0) __builtin_amdgcn_sched_barrier(0);      // the second half may mix with what follows (the pivot chain's idle slots)
   }
 }
 
