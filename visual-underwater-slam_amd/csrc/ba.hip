@@ -690,6 +690,10 @@ __device__ __forceinline__ const double* blk_ptr(const double* Sb, int band, int
   return Sb + 36 * ((size_t)i * (band + 1) + (i - k));
 }
 
+// the wave's index in its workgroup as a SCALAR: branches on it are scalar branches (derived from threadIdx.x alone the
+// compiler treats it as divergent and wraps every wave-specialised region in exec-mask saves and restores)
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {      // v of the lane the DPP control selects
   const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
@@ -762,7 +766,7 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
                                              double* lds_out = nullptr, double* lds_rhs_out = nullptr,
                                              double* lds_inv = nullptr) {
   [[maybe_unused]] const bool vus_wm_on = PUBLISH && k0 == 8 * 41 && blockIdx.x == 0;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int pb = min(PB, n_poses - k0);
   const int nb = 6 * pb;
   const int R = lane;                 // rows 0..nb-1: block rows; rows nb..nb+n_rhs-1: the right-hand sides
@@ -952,7 +956,7 @@ __device__ __forceinline__ void wg_barrier() {
 template <bool LDS_ONLY = false>
 __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* __restrict__ sM,
                                                const double* __restrict__ sInv) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
   // M_b = (16x16 diagonal block b)^-1 from its 8x8 quadrants:  [A 0; C B]^-1 = [A^-1 0; -B^-1 C A^-1  B^-1]
   if (tid < NB) {   // column n of the inverse of 8x8 diagonal block h by forward substitution (rows past nb: identity)
     const int h = tid >> 3, n = tid & 7;
@@ -1050,7 +1054,7 @@ __device__ __forceinline__ void block_inverses(double* __restrict__ sL, double* 
 template <bool LDS_ONLY = false>
 __device__ __forceinline__ void solve_rows(int n_tiles, double* __restrict__ Xa, double* __restrict__ Xb,
                                            const double* __restrict__ sL, const double* __restrict__ sM) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
   const int arow = lane & 15, kq = lane >> 4;
   // 16-row tiles: n_tiles * 3 of them, wave w takes tiles w and w + 4
   const int n16 = 3 * n_tiles;
@@ -1170,7 +1174,7 @@ __global__ __launch_bounds__(256) void chol_trsm_update_kernel(BandSet S, int ba
   __shared__ double sInv[NB];
   __shared__ int s_bad;
   VUS_TMARK(0);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
   // two systems: even blocks serve system 0, odd blocks system 1, so that both critical workgroups (bid 0) are
   // among the first blocks dispatched
   const int sysi = S.count == 2 ? (int)(blockIdx.x & 1) : 0;
@@ -1375,7 +1379,7 @@ __global__ __launch_bounds__(256, 4) void chol_syrk_kernel(BandSet S, int band, 
   __shared__ __attribute__((aligned(16))) double Xi[UT * ULD];
   __shared__ double Xj[UT * ULD];
   __shared__ int s_bad;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
   const int sysi = S.count == 2 ? (int)(blockIdx.x & 1) : 0;
   const int bid = S.count == 2 ? (int)(blockIdx.x >> 1) : (int)blockIdx.x;
   double* __restrict__ Sb = S.s[sysi].Sb;
@@ -1933,7 +1937,7 @@ __device__ __forceinline__ void win_store(rsrc_t rs, const WinLane& L, int band,
 
 // acc (an MFMA accumulator set holding MINUS the tile) += Xi * Xjj^T; a diagonal tile keeps its lower MFMA tiles only
 __device__ __forceinline__ void win_mfma_update(double4_t (&acc)[UQ], const double* Xi, const double* Xjj, bool diag) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = wave_index();
   const int arow = lane & 15, kq = lane >> 4;
 #pragma unroll
   for (int q = 0; q < UQ; ++q) {
@@ -1949,7 +1953,7 @@ __device__ __forceinline__ void win_mfma_update(double4_t (&acc)[UQ], const doub
 
 // ---- the critical workgroup of one system ----
 __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, double* smem, int& s_bad, int& s_go) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
   const int arow = lane & 15, kq = lane >> 4;
   const int n = B.n, NT = (n + PB - 1) / PB;
   double* Xi = smem;                       // sub-diagonal tile A -> X; the ring of panel_factor while a panel is factored
@@ -2144,7 +2148,7 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
 
 // ---- one window slot, for every system of the set ----
 __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs, double* smem, int& s_go) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
   const int arow = lane & 15, kq = lane >> 4;
   const int n = S.s[0].n, NT = (n + PB - 1) / PB;
   const int D = (band + PB - 1) / PB, M = D + 1;
