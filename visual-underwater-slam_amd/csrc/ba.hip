@@ -780,16 +780,42 @@ __device__ __forceinline__ void panel_factor(double* Sb, int n_poses, int band, 
     const int kb = wave + 4 * j;
 #pragma unroll
     for (int c = 0; c < 6; ++c) row[j][c] = 0.0;
-    if (bandidx::panel_row_ok(band, nb, R, kb)) {
-      // the offset into the band (64-bit arithmetic) only where the row really comes from memory
-      const double* src = (FROM_LDS && ii < lds_poses) ? lds_tile + R * LDD + 6 * kb : Sb + bandidx::panel_row(band, k0, nb, R, kb);
+    // PUBLISH: the whole panel comes from LDS (lds_poses = pb).  Kept apart at compile time: a pointer SELECTED between
+    // LDS and memory is a generic pointer and its loads FLAT loads (slower than ds_read, and they wait on both counters).
+    if constexpr (PUBLISH) {
+      if (bandidx::panel_row_ok(band, nb, R, kb)) {
+        const double* src = lds_tile + R * LDD + 6 * kb;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) row[j][c] = src[c];
-    }
-    if (is_rhs && kb < pb) {
-      const double* src = (FROM_LDS && kb < lds_poses) ? lds_rhs + (R - nb) * NB + 6 * kb : yrow + 6 * kb;
+        for (int c = 0; c < 6; ++c) row[j][c] = src[c];
+      }
+      if (is_rhs && kb < pb) {
+        const double* src = lds_rhs + (R - nb) * NB + 6 * kb;
 #pragma unroll
-      for (int c = 0; c < 6; ++c) row[j][c] = src[c];
+        for (int c = 0; c < 6; ++c) row[j][c] = src[c];
+      }
+    } else {
+      typedef const __attribute__((address_space(3))) double* lds_cptr;      // keeps the two sources' loads apart
+      if (bandidx::panel_row_ok(band, nb, R, kb)) {
+        if (FROM_LDS && ii < lds_poses) {
+          lds_cptr src = (lds_cptr)(lds_tile + R * LDD + 6 * kb);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) row[j][c] = src[c];
+        } else {      // the offset into the band (64-bit arithmetic) only where the row really comes from memory
+          const double* src = Sb + bandidx::panel_row(band, k0, nb, R, kb);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) row[j][c] = src[c];
+        }
+      }
+      if (is_rhs && kb < pb) {
+        if (FROM_LDS && kb < lds_poses) {
+          lds_cptr src = (lds_cptr)(lds_rhs + (R - nb) * NB + 6 * kb);
+#pragma unroll
+          for (int c = 0; c < 6; ++c) row[j][c] = src[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 6; ++c) row[j][c] = yrow[6 * kb + c];
+        }
+      }
     }
   }
   __syncthreads();
