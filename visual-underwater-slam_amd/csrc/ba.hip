@@ -2661,7 +2661,7 @@ bool window_applicable(const BandSet& S, int band, int n_elim) {
   return M * (M + 1) / 2 + 2 * S.count <= window_capacity();
 }
 
-int window_launch(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st) {
+int window_launch(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st, bool flags_cleared = false) {
   const int n = S.s[0].n, NT = (n + PB - 1) / PB;
   const int NE = n_elim >= n ? NT : n_elim / PB;
   const int D = (band + PB - 1) / PB, M = D + 1;
@@ -2671,8 +2671,9 @@ int window_launch(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t
     const BandSys& b = S.s[q < S.count ? q : 0];
     W.s[q] = WinSys{b.Sb, b.y, b.status, b.win_pub, b.win_F, b.n};
   }
-  for (int q = 0; q < S.count; ++q)
-    VUS_CHECK_HIP(hipMemsetAsync(S.s[q].win_F, 0, sizeof(int) * (size_t)(2 + 2 * NT), st));
+  if (!flags_cleared)
+    for (int q = 0; q < S.count; ++q)
+      VUS_CHECK_HIP(hipMemsetAsync(S.s[q].win_F, 0, sizeof(int) * (size_t)(2 + 2 * NT), st));
   const int lds = WIN_LDS_DOUBLES * (int)sizeof(double);
   VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(chol_window_kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, lds));
@@ -2687,7 +2688,8 @@ int window_launch(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t
 // eliminated (n_elim == S.s[0].n: the whole matrix; smaller, a multiple of PB: a PARTIAL factorisation that leaves the
 // Schur complement of the eliminated poses in the trailing window and the forward-substituted right-hand sides
 // in y).  The forward substitution rides along.
-int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st, hipStream_t st2 = nullptr) {
+int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t st, hipStream_t st2 = nullptr,
+                    bool flags_cleared = false) {
   const int n = S.s[0].n;
   const bool full = n_elim >= n;
   // Three ways to issue a panel step (the knob VUS_TUNE_BAND_MODE = 0 / 1 / 2 forces one; tests and A/B timing):
@@ -2704,7 +2706,7 @@ int factor_launches(const BandSet& S, int band, int n_elim, int n_rhs, hipStream
     const int m = g_knobs.band_mode.load(std::memory_order_relaxed);
     if ((m < 0 || m == 3) && window_applicable(S, band, full ? n : n_elim)) {
       g_knobs.last_mode = 3;
-      return window_launch(S, band, full ? n : n_elim, n_rhs, st);
+      return window_launch(S, band, full ? n : n_elim, n_rhs, st, flags_cleared);
     }
     if (m == 0 || m == 1 || (m == 2 && S.count == 2 && st2)) mode = m;
   }
@@ -2833,7 +2835,8 @@ bool diag_invert_launch(const BandSet& S, int band, int n_solve, hipStream_t st)
   return true;
 }
 
-int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st, bool pre_inverted = false) {
+int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st, bool pre_inverted = false,
+                     bool flags_cleared = false) {
   // flags of the cooperative sweep live in the unused slots of block row 0 (blocks (0, k < 0))
   const int n_groups = band > 0 ? (band + PB - 1) / PB : 1;
   VUS_REQUIRE(band == 0 || 2 + n_groups <= 72 * band, "band=%d: too many row groups for the flag area", band);
@@ -2841,7 +2844,7 @@ int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st
     S.s[q].F = band > 0 ? reinterpret_cast<int*>(S.s[q].Sb + 36) : flags_fallback();
     VUS_REQUIRE(S.s[q].F != nullptr, "no scratch for the solver flags");
     VUS_REQUIRE(band > 0 || S.count == 1, "two band-0 systems cannot share the fallback flags");
-    VUS_CHECK_HIP(hipMemsetAsync(S.s[q].F, 0, sizeof(int) * (size_t)(2 + n_groups), st));
+    if (!flags_cleared) VUS_CHECK_HIP(hipMemsetAsync(S.s[q].F, 0, sizeof(int) * (size_t)(2 + n_groups), st));
   }
   const int inverted = pre_inverted ? 1 : (int)diag_invert_launch(S, band, n_solve, st);
   // at most backsolve_max_wg() cooperating workgroups in total, so that all of them are resident at once
@@ -2853,9 +2856,11 @@ int backsolve_launch(BandSet S, int band, int n_rhs, int n_solve, hipStream_t st
   return VUS_OK;
 }
 
+// flags_cleared: the caller has zeroed the status word, the window kernel's flags and the back-substitution's flag words
+// (the unused slots of block row 0, Sband + 36) in a launch of its own.
 int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, int* status, hipStream_t st,
-                    double* win_scratch = nullptr) {
-  VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
+                    double* win_scratch = nullptr, bool flags_cleared = false) {
+  if (!flags_cleared) VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
   BandSet S;
   S.count = 1;
   S.s[0] = BandSys{Sband, y, status, nullptr, n_nodes};
@@ -2864,8 +2869,8 @@ int band_solve_impl(double* Sband, int n_nodes, int band, double* y, int n_rhs, 
     S.s[0].win_F = reinterpret_cast<int*>(win_scratch + (size_t)((n_nodes + PB - 1) / PB) * WIN_PUB);
   }
   S.s[1] = S.s[0];
-  if (int rc = factor_launches(S, band, n_nodes, n_rhs, st)) return rc;
-  return backsolve_launch(S, band, n_rhs, 0, st);
+  if (int rc = factor_launches(S, band, n_nodes, n_rhs, st, nullptr, flags_cleared)) return rc;
+  return backsolve_launch(S, band, n_rhs, 0, st, false, flags_cleared && band > 0);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -2905,12 +2910,29 @@ bool split_plan(int n, int band, int n_rhs, SplitPlan& p) {
   return true;
 }
 
+// Every flag word and status word of a two-sided solve, zeroed by its first kernel instead of by a memset launch each
+// (nine launches of ~5 us on the solve's critical path).
+struct ClearList {
+  int* p[8];
+  int n[8];
+  int count = 0;
+  void add(int* q, size_t k) {
+    p[count] = q;
+    n[count++] = (int)k;
+  }
+};
+
 // Rb(i', s) = transpose of Sband(n-1-i'+s, s) -- the pose-reversed matrix in the same lower-band layout -- except the
 // middle x middle region (both reversed poses >= m), which starts from zero; yT = y[.. nT), yR = reversed y, zero on
 // the middle poses.
-__global__ void split_prepare_kernel(const double* __restrict__ Sband, const double* __restrict__ y, SplitPlan p,
-                                     double* __restrict__ Rb, double* __restrict__ yT, double* __restrict__ yR) {
+// cl: the solve's flag and status words (one of them inside Sband: the unused slots of block row 0, which this kernel
+// does not read).
+__global__ void split_prepare_kernel(const double* Sband, const double* __restrict__ y, SplitPlan p,
+                                     double* __restrict__ Rb, double* __restrict__ yT, double* __restrict__ yR, ClearList cl) {
   const size_t t = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  for (int k = 0; k < cl.count; ++k)
+    if (blockIdx.x == (unsigned)k % gridDim.x)
+      for (int i = threadIdx.x; i < cl.n[k]; i += blockDim.x) cl.p[k][i] = 0;
   const size_t nR = 36 * (size_t)p.nT * (p.band + 1);
   if (t < nR) {
     const int e = (int)(t % 36);
@@ -3036,10 +3058,6 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
   double* yM = work + p.off_yM;
   int* st_R = reinterpret_cast<int*>(work + p.off_int);
   int* st_M = st_R + 2;
-  VUS_CHECK_HIP(hipMemsetAsync(status, 0, sizeof(int), st));
-  VUS_CHECK_HIP(hipMemsetAsync(st_R, 0, 4 * sizeof(int), st));
-  const size_t nR = 36 * (size_t)p.nT * (band + 1);
-  split_prepare_kernel<<<cdiv((long long)nR, 256), 256, 0, st>>>(Sband, y, p, Rb, yT, yR);
   BandSet S;
   S.count = 2;
   S.s[0] = BandSys{Sband, yT, status, nullptr, p.nT};
@@ -3051,6 +3069,21 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
       S.s[q].win_F = reinterpret_cast<int*>(w[q] + (size_t)(p.m / PB) * WIN_PUB);
     }
   }
+  // Status words, the window kernels' flags (halves and middle system) and the flag words of the halves' and the middle
+  // system's back-substitution are zeroed by split_prepare_kernel.  The back-substitution's words are the unused slots of
+  // block row 0 (Sb + 36): the top half's are cleared explicitly; the reversed copy and the middle system are written
+  // whole by split_prepare_kernel / split_mid_kernel, zeros in every slot the band does not store.
+  ClearList cl;
+  const int NT_half = (p.nT + PB - 1) / PB, NT_mid = (p.n_mid + PB - 1) / PB;
+  double* winM = work + p.off_winM;
+  cl.add(status, 1);
+  cl.add(st_R, 4);
+  cl.add(S.s[0].win_F, 2 + 2 * (size_t)NT_half);
+  cl.add(S.s[1].win_F, 2 + 2 * (size_t)NT_half);
+  cl.add(reinterpret_cast<int*>(winM + (size_t)NT_mid * WIN_PUB), 2 + 2 * (size_t)NT_mid);
+  cl.add(reinterpret_cast<int*>(Sband + 36), 2 + (size_t)((band + PB - 1) / PB));
+  const size_t nR = 36 * (size_t)p.nT * (band + 1);
+  split_prepare_kernel<<<cdiv((long long)nR, 256), 256, 0, st>>>(Sband, y, p, Rb, yT, yR, cl);
   // the halves are independent chains until the middle system: the pose-reversed one runs on a second stream
   const int mode_knob = g_knobs.band_mode.load(std::memory_order_relaxed);
   SplitSection sec((mode_knob < 0 || mode_knob >= 2) ? split_aux(st) : nullptr, st);
@@ -3058,7 +3091,7 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
   const bool halves_on_two_streams = sec.a && !((mode_knob < 0 || mode_knob == 3) && window_applicable(S, band, p.m));
   if (halves_on_two_streams)
     if (int rc = sec.fork()) return rc;
-  if (int rc = factor_launches(S, band, p.m, n_rhs, st, halves_on_two_streams ? sec.a->s2 : nullptr)) return rc;
+  if (int rc = factor_launches(S, band, p.m, n_rhs, st, halves_on_two_streams ? sec.a->s2 : nullptr, true)) return rc;
   if (halves_on_two_streams)
     if (int rc = sec.join()) return rc;
   // the diagonal panels of both halves are inverted (for their back-substitution) beside the middle system's solve
@@ -3069,12 +3102,12 @@ int band_solve_split_impl(double* Sband, int n, int band, double* y, int n_rhs, 
   }
   const size_t nM = 36 * (size_t)p.n_mid * (p.bm + 1);
   split_mid_kernel<<<cdiv((long long)nM, 256), 256, 0, st>>>(Sband, y, p, Rb, yT, yR, Mid, yM);
-  if (int rc = band_solve_impl(Mid, p.n_mid, p.bm, yM, n_rhs, st_M, st, work + p.off_winM)) return rc;
+  if (int rc = band_solve_impl(Mid, p.n_mid, p.bm, yM, n_rhs, st_M, st, work + p.off_winM, true)) return rc;
   const int n_spike = band < p.m ? band : p.m;
   split_spike_kernel<<<dim3(n_spike, 2, n_rhs), 64, 0, st>>>(Sband, Rb, p, yM, yT, yR);
   if (sec.open)
     if (int rc = sec.join()) return rc;
-  if (int rc = backsolve_launch(S, band, n_rhs, p.m, st, halves_inverted)) return rc;     // the eliminated poses of both halves
+  if (int rc = backsolve_launch(S, band, n_rhs, p.m, st, halves_inverted, true)) return rc;     // the eliminated poses of both halves
   split_gather_kernel<<<cdiv(6ll * n * n_rhs, 256), 256, 0, st>>>(p, yT, yR, yM, y, st_R, st_M, status);
   VUS_CHECK_LAUNCH("ba_band_solve_split");
   return VUS_OK;
