@@ -1,0 +1,16 @@
+#!/bin/bash
+# Build a variant of the library for same-box A/B timing (no GPU needed):
+#   tools/ab/build_variant.sh NAME "-DSOME_SWITCH"  ->  tools/ab/libvus_n_NAME.so (plain) and libvus_t_NAME.so (-DVUS_TIMING)
+# Only ba.hip is rebuilt; the other objects come from visual-underwater-slam_amd/csrc (run make there first).
+# The .so files are git-ignored and travel to the GPU box with gpurun; delete them when the experiment is over.
+set -e
+HERE=$(cd "$(dirname "$0")" && pwd)
+cd "$HERE/../../visual-underwater-slam_amd/csrc"
+name=$1; flags=$2
+mkdir -p /tmp/tb_$name
+for kind in n t; do
+  extra=""; [ $kind = t ] && extra="-DVUS_TIMING"
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $extra $flags -c ba.hip -o /tmp/tb_$name/ba_$kind.o \
+    && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 vus_common.o frontend.o /tmp/tb_$name/ba_$kind.o structure.o nav.o pack.o -o "$HERE/libvus_${kind}_$name.so" ) &
+done
+wait

@@ -26,6 +26,7 @@ python3 $ROOT/tools/summarize_stats.py /tmp/prof_py 40 | grep -v "at::native\|ro
 # 4. BA kernels at configs[2]: stats of three linear solves + PMC passes (VALU / LDS / MFMA / L1-L2 / HBM, separate passes)
 rm -rf /tmp/prof_ba && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_ba -- python3 $ROOT/tools/ba_profile.py > /dev/null 2>&1 || true
 python3 $ROOT/tools/summarize_stats.py /tmp/prof_ba 40 | grep -v "at::native\|rocprim\|rocclr\|compute_cuda" > $OUT/kernel_stats_ba_${TAG}.txt || true
+python3 $ROOT/tools/kernel_timeline.py /tmp/prof_ba > $OUT/timeline_ba_${TAG}.txt || true      # the last solve, kernel by kernel
 bash $ROOT/tools/pmc_ba.sh $OUT/pmc_ba_${TAG}.txt || true
 # 5. VALU issue-rate micro-benchmark (what bounds the FAST kernel) and the f64 matrix / vector rates (BA rooflines)
 /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 $ROOT/tools/ubench/valu_rate.hip -o /tmp/valu_rate 2>/dev/null && /tmp/valu_rate > $OUT/valu_issue_rates_${TAG}.txt || true
@@ -39,4 +40,9 @@ python3 $ROOT/tools/overlap_probe.py 2>/dev/null | tail -2 > $OUT/schur_band_ove
 #    kernel), and the first optimize() of a process by phase
 python3 $ROOT/tools/band_modes_probe.py 2 3 2>/dev/null | grep '^{' > $OUT/band_modes_${TAG}.txt || true
 python3 $ROOT/tools/cold_phases.py 2>/dev/null | grep '^{' > $OUT/cold_phases_${TAG}.txt || true
+# 8. where a panel step of the window kernel's critical workgroup goes: s_memtime marks of a -DVUS_TIMING build of the library
+CS=$ROOT/visual-underwater-slam_amd/csrc
+mkdir -p /tmp/tb && (cd $CS && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DVUS_TIMING -c ba.hip -o /tmp/tb/ba_t.o 2>/dev/null \
+  && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 vus_common.o frontend.o /tmp/tb/ba_t.o structure.o nav.o pack.o -o /tmp/tb/libvus_timing.so) \
+  && VUS_HIP_LIB=/tmp/tb/libvus_timing.so python3 $ROOT/tools/win_timing.py 2>/dev/null | grep '^{' > $OUT/window_step_cycles_${TAG}.txt || true
 ls -la $OUT
