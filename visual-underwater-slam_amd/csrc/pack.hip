@@ -9,10 +9,12 @@
 //                              permutations and both pointer arrays of vus_ba_problem
 //   vus_exclusive_scan_i32     row counts -> offsets + 64-bit total (the structure builder's list sizes)
 //
-// The sorts are rocPRIM's device radix sort (a ROCm library primitive compiled into this library: index plumbing, not
-// arithmetic of the path); everything around them is small HIP kernels.  All results stay on the device.
+// The sorts are a stable LSD radix sort written here (8-bit digits: per-tile histograms, one scan, a stable scatter that
+// ranks equal digits with wave ballots).  Round 3 first used rocPRIM's device radix sort: faster per call (0.5 ms against
+// 0.9 ms for a configs[2] graph), but its template instantiations made this translation unit's code object 6.8 MB -- 4 MB of
+// it mangled names -- and LOADING it cost the first optimize() of a process 23 ms (tools/cold_pack_probe.py); batch.py:337
+// calls optimize() exactly once per process.  All results stay on the device.
 #include <cstring>
-#include <rocprim/rocprim.hpp>
 #include "vus_common.h"
 
 namespace {
@@ -23,12 +25,6 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 __global__ void iota_kernel(int* __restrict__ a, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) a[i] = i;
-}
-
-// head[i] = 1 where a new key starts in the sorted sequence
-__global__ void head_flags_kernel(const unsigned long long* __restrict__ sk, int n, int* __restrict__ head) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) head[i] = (i == 0 || sk[i] != sk[i - 1]) ? 1 : 0;
 }
 
 // rank[i] = inclusive scan of head: the key of sorted position i is the (rank[i] - 1)-th distinct key
@@ -163,6 +159,244 @@ __global__ __launch_bounds__(1024) void scan_i32_kernel(const int* __restrict__ 
   }
 }
 
+// ---- stable LSD radix sort of (key, int value) pairs, 8 bits per pass -------------------------------------------------
+// A tile = RS_TILE consecutive elements handled by one workgroup in both kernels of a pass, so that the histogram's
+// counts are exactly what the scatter places.  counts / offsets are laid out [digit][tile]: one exclusive scan over the
+// whole table gives every (digit, tile) its first output position, and the order digit-major / tile-minor / element
+// order inside the tile is what makes the pass stable.
+constexpr int RS_THREADS = 256, RS_ITEMS = 16, RS_TILE = RS_THREADS * RS_ITEMS;
+
+// vary |= key ^ key[0] over all keys: a pass whose digit is the same in every key (the upper bytes of gtsam keys
+// chr << 56 | index) has nothing to reorder -- its kernels see that in `vary` and the scatter degenerates to a copy.
+template <class Key>
+__global__ __launch_bounds__(RS_THREADS) void rs_vary_kernel(const Key* __restrict__ keys, int n, unsigned long long* __restrict__ vary) {
+  const Key k0 = keys[0];
+  unsigned long long v = 0;
+  for (long long idx = (long long)blockIdx.x * RS_THREADS + threadIdx.x; idx < n; idx += (long long)gridDim.x * RS_THREADS)
+    v |= (unsigned long long)(keys[idx] ^ k0);
+  for (int o = 32; o > 0; o >>= 1) v |= __shfl_down(v, o, 64);
+  if ((threadIdx.x & 63) == 0 && v != 0) atomicOr(vary, v);
+}
+
+__device__ __forceinline__ bool rs_skip(const unsigned long long* vary, int shift, unsigned mask) {
+  return ((unsigned)(vary[0] >> shift) & mask) == 0;
+}
+
+template <class Key>
+__global__ __launch_bounds__(RS_THREADS) void rs_hist_kernel(const Key* __restrict__ keys, int n, int shift, unsigned mask,
+                                                             int* __restrict__ counts, int n_tiles,
+                                                             const unsigned long long* __restrict__ vary) {
+  if (rs_skip(vary, shift, mask)) return;
+  __shared__ int h[256];
+  const int tid = threadIdx.x;
+  h[tid] = 0;
+  __syncthreads();
+  const long long base = (long long)blockIdx.x * RS_TILE;
+#pragma unroll 4
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const long long idx = base + i * RS_THREADS + tid;
+    if (idx < n) atomicAdd(&h[(unsigned)(keys[idx] >> shift) & mask], 1);
+  }
+  __syncthreads();
+  counts[tid * n_tiles + blockIdx.x] = h[tid];
+}
+
+// workgroup d: counts[d][0 .. n_tiles) -> exclusive prefix over the tiles, in place; totals[d] = the digit's count
+__global__ __launch_bounds__(RS_THREADS) void rs_scan_kernel(int* __restrict__ counts, int n_tiles, int* __restrict__ totals, int shift,
+                                                             unsigned mask, const unsigned long long* __restrict__ vary) {
+  if (rs_skip(vary, shift, mask)) return;
+  __shared__ int s_t[RS_THREADS];
+  const int tid = threadIdx.x;
+  int* row = counts + (size_t)blockIdx.x * n_tiles;
+  const int per = (n_tiles + RS_THREADS - 1) / RS_THREADS;
+  int local = 0;
+  for (int u = 0; u < per; ++u) {
+    const int i = tid * per + u;
+    if (i < n_tiles) local += row[i];
+  }
+  s_t[tid] = local;
+  __syncthreads();
+  for (int o = 1; o < RS_THREADS; o <<= 1) {
+    const int v = tid >= o ? s_t[tid - o] : 0;
+    __syncthreads();
+    s_t[tid] += v;
+    __syncthreads();
+  }
+  int run = s_t[tid] - local;
+  for (int u = 0; u < per; ++u) {
+    const int i = tid * per + u;
+    if (i < n_tiles) {
+      const int c = row[i];
+      row[i] = run;
+      run += c;
+    }
+  }
+  if (tid == RS_THREADS - 1) totals[blockIdx.x] = s_t[tid];
+}
+
+template <class Key>
+__global__ __launch_bounds__(RS_THREADS) void rs_scatter_kernel(const Key* __restrict__ kin, const int* __restrict__ vin,
+                                                                Key* __restrict__ kout, int* __restrict__ vout, int n, int shift,
+                                                                unsigned mask, const int* __restrict__ tile_prefix,
+                                                                const int* __restrict__ totals, int n_tiles,
+                                                                const unsigned long long* __restrict__ vary) {
+  __shared__ int s_next[256];                    // output position of the tile's next element of each digit
+  __shared__ int s_wc[RS_THREADS / 64][256];     // elements of each digit in each wave of the current row of 256
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long base = (long long)blockIdx.x * RS_TILE;
+  if (rs_skip(vary, shift, mask)) {              // nothing to reorder: the tile is copied
+    for (int i = 0; i < RS_ITEMS; ++i) {
+      const long long idx = base + i * RS_THREADS + tid;
+      if (idx < n) {
+        kout[idx] = kin[idx];
+        vout[idx] = vin[idx];
+      }
+    }
+    return;
+  }
+  // first position of digit d = number of elements with a smaller digit: exclusive scan of the 256 totals
+  const int tot = totals[tid];
+  s_next[tid] = tot;
+  __syncthreads();
+  for (int o = 1; o < 256; o <<= 1) {
+    const int v = tid >= o ? s_next[tid - o] : 0;
+    __syncthreads();
+    s_next[tid] += v;
+    __syncthreads();
+  }
+  const int first = s_next[tid] - tot;
+  __syncthreads();
+  s_next[tid] = first + tile_prefix[tid * n_tiles + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < RS_THREADS / 64; ++w) s_wc[w][tid] = 0;
+  __syncthreads();
+  const unsigned long long lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const long long idx = base + i * RS_THREADS + tid;
+    const bool valid = idx < n;
+    const Key key = valid ? kin[idx] : (Key)0;
+    const int val = valid ? vin[idx] : 0;
+    const unsigned d = (unsigned)(key >> shift) & mask;
+    // the lanes of this wave holding the same digit (eight ballots), this lane's place among them
+    unsigned long long same = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const unsigned long long bal = __ballot(bit);
+      same &= bit ? bal : ~bal;
+    }
+    const int rank_w = __popcll(same & lt);
+    if (valid && rank_w == 0) s_wc[wave][d] = __popcll(same);
+    __syncthreads();
+    if (valid) {
+      int before = 0;
+#pragma unroll
+      for (int w = 0; w < RS_THREADS / 64; ++w) before += w < wave ? s_wc[w][d] : 0;
+      const int pos = s_next[d] + before + rank_w;
+      kout[pos] = key;
+      vout[pos] = val;
+    }
+    __syncthreads();
+    int row = 0;
+#pragma unroll
+    for (int w = 0; w < RS_THREADS / 64; ++w) {
+      row += s_wc[w][tid];
+      s_wc[w][tid] = 0;
+    }
+    s_next[tid] += row;
+    __syncthreads();
+  }
+}
+
+inline int rs_tiles(int n) { return n > 0 ? (n + RS_TILE - 1) / RS_TILE : 1; }
+inline int rs_passes(int end_bit) { return end_bit > 0 ? (end_bit + 7) / 8 : 1; }
+
+// scratch of one sort: a key array, a value array (ping-pong partners of the outputs), the count table [256][tiles], the
+// digit totals and the word of varying key bits
+struct SortTemp {
+  void* keys;
+  int* vals;
+  int* counts;
+  int* offsets;          // [0, 256): digit totals; the rest: scratch of the callers' own scans
+  long long* total;      // the word of varying key bits during a sort; a scan's 64-bit total otherwise
+};
+
+// Sorts the low end_bit bits of the keys, stable.  The inputs are only read; the last pass writes (kout, vout).
+template <class Key>
+int radix_sort_pairs(const Key* kin, Key* kout, const int* vin, int* vout, int n, int end_bit, const SortTemp& t, hipStream_t st) {
+  const int passes = rs_passes(end_bit), nt = rs_tiles(n);
+  Key* ktmp = static_cast<Key*>(t.keys);
+  unsigned long long* vary = reinterpret_cast<unsigned long long*>(t.total);
+  VUS_CHECK_HIP(hipMemsetAsync(vary, 0, sizeof(unsigned long long), st));
+  rs_vary_kernel<Key><<<nt < 1024 ? nt : 1024, RS_THREADS, 0, st>>>(kin, n, vary);
+  const Key* ks = kin;
+  const int* vs = vin;
+  for (int p = 0; p < passes; ++p) {
+    const bool to_out = ((passes - 1 - p) & 1) == 0;
+    Key* kd = to_out ? kout : ktmp;
+    int* vd = to_out ? vout : t.vals;
+    const int bits = end_bit - 8 * p < 8 ? end_bit - 8 * p : 8;
+    const unsigned mask = (1u << bits) - 1u;
+    rs_hist_kernel<Key><<<nt, RS_THREADS, 0, st>>>(ks, n, 8 * p, mask, t.counts, nt, vary);
+    rs_scan_kernel<<<256, RS_THREADS, 0, st>>>(t.counts, nt, t.offsets, 8 * p, mask, vary);
+    rs_scatter_kernel<Key><<<nt, RS_THREADS, 0, st>>>(ks, vs, kd, vd, n, 8 * p, mask, t.counts, t.offsets, nt, vary);
+    ks = kd;
+    vs = vd;
+  }
+  VUS_CHECK_LAUNCH("radix_sort_pairs");
+  return VUS_OK;
+}
+
+// ---- rank of every sorted position among the distinct keys: inclusive scan of the head flags, tile sums first ----------
+__global__ __launch_bounds__(RS_THREADS) void head_sums_kernel(const unsigned long long* __restrict__ sk, int n, int* __restrict__ tile_sum) {
+  __shared__ int s_w[RS_THREADS / 64];
+  const int tid = threadIdx.x;
+  const long long base = (long long)blockIdx.x * RS_TILE;
+  int c = 0;
+#pragma unroll 4
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const long long idx = base + i * RS_THREADS + tid;
+    if (idx < n) c += (idx == 0 || sk[idx] != sk[idx - 1]) ? 1 : 0;
+  }
+  for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+  if ((tid & 63) == 0) s_w[tid >> 6] = c;
+  __syncthreads();
+  if (tid == 0) {
+    int t = 0;
+    for (int w = 0; w < RS_THREADS / 64; ++w) t += s_w[w];
+    tile_sum[blockIdx.x] = t;
+  }
+}
+
+// rank[i] = number of heads in [0, i]; a thread owns RS_ITEMS CONSECUTIVE elements of the tile
+__global__ __launch_bounds__(RS_THREADS) void head_ranks_kernel(const unsigned long long* __restrict__ sk, int n,
+                                                                const int* __restrict__ tile_off, int* __restrict__ rank) {
+  __shared__ int s_t[RS_THREADS];
+  const int tid = threadIdx.x;
+  const long long first = (long long)blockIdx.x * RS_TILE + (long long)tid * RS_ITEMS;
+  int c = 0;
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const long long idx = first + i;
+    if (idx < n) c += (idx == 0 || sk[idx] != sk[idx - 1]) ? 1 : 0;
+  }
+  s_t[tid] = c;
+  __syncthreads();
+  for (int o = 1; o < RS_THREADS; o <<= 1) {
+    const int v = tid >= o ? s_t[tid - o] : 0;
+    __syncthreads();
+    s_t[tid] += v;
+    __syncthreads();
+  }
+  int run = tile_off[blockIdx.x] + s_t[tid] - c;
+  for (int i = 0; i < RS_ITEMS; ++i) {
+    const long long idx = first + i;
+    if (idx < n) {
+      run += (idx == 0 || sk[idx] != sk[idx - 1]) ? 1 : 0;
+      rank[idx] = run;
+    }
+  }
+}
+
 int bits_for(unsigned long long max_value) {
   int b = 1;
   while (b < 64 && (max_value >> b) != 0) ++b;
@@ -183,15 +417,20 @@ struct Carve {
   }
 };
 
+// bytes of a SortTemp for n elements (carved by take_sort_temp)
 size_t sort_temp_bytes(int n) {
-  size_t b64 = 0, b32 = 0, bs = 0;
-  (void)rocprim::radix_sort_pairs(nullptr, b64, (const unsigned long long*)nullptr, (unsigned long long*)nullptr,
-                                  (const int*)nullptr, (int*)nullptr, (size_t)n, 0, 64);
-  (void)rocprim::radix_sort_pairs(nullptr, b32, (const unsigned int*)nullptr, (unsigned int*)nullptr, (const int*)nullptr,
-                                  (int*)nullptr, (size_t)n, 0, 32);
-  (void)rocprim::inclusive_scan(nullptr, bs, (const int*)nullptr, (int*)nullptr, (size_t)n, rocprim::plus<int>());
-  size_t m = b64 > b32 ? b64 : b32;
-  return m > bs ? m : bs;
+  const size_t nt = (size_t)rs_tiles(n);
+  return align256(8 * (size_t)n) + align256(4 * (size_t)n) + 2 * align256(4 * (256 * nt + 1)) + align256(8);
+}
+
+bool take_sort_temp(Carve& c, int n, SortTemp& t) {
+  const size_t nt = (size_t)rs_tiles(n);
+  t.keys = c.take<unsigned long long>(n);
+  t.vals = c.take<int>(n);
+  t.counts = c.take<int>(256 * nt + 1);
+  t.offsets = c.take<int>(256 * nt + 1);
+  t.total = c.take<long long>(1);
+  return t.keys && t.vals && t.counts && t.offsets && t.total;
 }
 
 }  // namespace
@@ -199,8 +438,8 @@ size_t sort_temp_bytes(int n) {
 extern "C" long long vus_pack_work_bytes(int n) {
   if (n < 0) return 0;
   const size_t nn = (size_t)(n > 0 ? n : 1);
-  // two 8-byte key arrays, four 4-byte index arrays, the library's own temporary storage
-  return (long long)(2 * align256(8 * nn) + 4 * align256(4 * nn) + align256(sort_temp_bytes(n > 0 ? n : 1)) + 1024);
+  // two 8-byte key arrays, four 4-byte index arrays, the sort's own temporary storage
+  return (long long)(2 * align256(8 * nn) + 4 * align256(4 * nn) + sort_temp_bytes(n > 0 ? n : 1) + 1024);
 }
 
 extern "C" int vus_keys_to_indices(const int64_t* keys, int n, int* idx_out, int64_t* uniq_out, int* n_unique, void* work,
@@ -219,18 +458,18 @@ extern "C" int vus_keys_to_indices(const int64_t* keys, int n, int* idx_out, int
   c.take<unsigned long long>(n);
   int* iota = c.take<int>(n);
   int* sp = c.take<int>(n);
-  int* head = c.take<int>(n);
+  int* tile_sum = c.take<int>(n);          // rs_tiles(n) + 1 entries used of each
   int* rank = c.take<int>(n);
-  size_t tb = sort_temp_bytes(n);
-  void* tmp = c.take<char>(tb);
-  VUS_REQUIRE(sk && iota && sp && head && rank && tmp, "workspace too small");
+  SortTemp tmp;
+  VUS_REQUIRE(sk && iota && sp && tile_sum && rank && take_sort_temp(c, n, tmp), "workspace too small");
   iota_kernel<<<cdiv(n, 256), 256, 0, st>>>(iota, n);
   // gtsam keys are non-negative (chr << 56 | index): their unsigned order is their order
-  VUS_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tb, reinterpret_cast<const unsigned long long*>(keys), sk, iota, sp, (size_t)n,
-                                          0, 64, st));
-  head_flags_kernel<<<cdiv(n, 256), 256, 0, st>>>(sk, n, head);
-  size_t sb = tb;
-  VUS_CHECK_HIP(rocprim::inclusive_scan(tmp, sb, head, rank, (size_t)n, rocprim::plus<int>(), st));
+  if (int rc = radix_sort_pairs<unsigned long long>(reinterpret_cast<const unsigned long long*>(keys), sk, iota, sp, n, 64, tmp, st))
+    return rc;
+  const int nt = rs_tiles(n);
+  head_sums_kernel<<<nt, RS_THREADS, 0, st>>>(sk, n, tile_sum);
+  scan_i32_kernel<<<1, 1024, 0, st>>>(tile_sum, nt, tmp.offsets, tmp.total);
+  head_ranks_kernel<<<nt, RS_THREADS, 0, st>>>(sk, n, tmp.offsets, rank);
   scatter_ranks_kernel<<<cdiv(n, 256), 256, 0, st>>>(sk, sp, rank, n, idx_out, reinterpret_cast<long long*>(uniq_out), n_unique);
   VUS_CHECK_LAUNCH("keys_to_indices");
   return VUS_OK;
@@ -276,22 +515,20 @@ extern "C" int vus_ba_pack_observations(const int* obs_pose, const int* obs_poin
   int* spose = c.take<int>(n);
   c.take<int>(n);
   c.take<int>(n);
-  size_t tb = sort_temp_bytes(n);
-  void* tmp = c.take<char>(tb);
-  VUS_REQUIRE(key && sk && iota && spose && tmp, "workspace too small");
+  SortTemp tmp;
+  VUS_REQUIRE(key && sk && iota && spose && take_sort_temp(c, n, tmp), "workspace too small");
   iota_kernel<<<cdiv(n, 256), 256, 0, st>>>(iota, n);
   make_keys_kernel<<<cdiv(n, 256), 256, 0, st>>>(obs_pose, obs_point, n, n_poses, n_points, key, flags);
   // L-order: by (point, pose).  Keys are unique in a valid graph, so the order is total.
   const int kbits = bits_for((unsigned long long)(n_points > 0 ? n_points : 1) * (unsigned long long)n_poses);
-  VUS_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tb, key, sk, iota, perm, (size_t)n, 0, kbits, st));
+  if (int rc = radix_sort_pairs<unsigned long long>(key, sk, iota, perm, n, kbits, tmp, st)) return rc;
   gather_L_kernel<<<cdiv(n, 256), 256, 0, st>>>(sk, perm, meas, n, n_poses, meas_L, obs_pose_L, obs_point_L, flags);
   point_ptr_kernel<<<cdiv(n_points + 1, 256), 256, 0, st>>>(sk, n, n_poses, n_points, point_ptr);
   if (band && n_points > 0) band_kernel<<<cdiv(n_points, 256), 256, 0, st>>>(point_ptr, obs_pose_L, n_points, band);
   // P-order: a STABLE sort of the L-order rows by pose keeps the points ascending inside every pose
-  size_t tb2 = tb;
-  VUS_CHECK_HIP(rocprim::radix_sort_pairs(tmp, tb2, reinterpret_cast<const unsigned int*>(obs_pose_L),
-                                          reinterpret_cast<unsigned int*>(spose), iota, pobs_lidx, (size_t)n, 0,
-                                          bits_for((unsigned long long)n_poses), st));
+  if (int rc = radix_sort_pairs<unsigned int>(reinterpret_cast<const unsigned int*>(obs_pose_L), reinterpret_cast<unsigned int*>(spose),
+                                              iota, pobs_lidx, n, bits_for((unsigned long long)n_poses), tmp, st))
+    return rc;
   inverse_perm_kernel<<<cdiv(n, 256), 256, 0, st>>>(pobs_lidx, n, obs_ppos);
   pose_ptr_kernel<<<cdiv(n_poses + 1, 256), 256, 0, st>>>(spose, n, n_poses, pose_ptr);
   VUS_CHECK_LAUNCH("ba_pack_observations");
