@@ -131,6 +131,52 @@ def test_device_key_maps_equal_numpy(gpu):
 
 
 @pytest.mark.gpu
+def test_device_key_sort_covers_every_digit(gpu):
+    """The radix sort behind vus_keys_to_indices, on keys that vary in every byte (keys of several symbol characters, and
+    arbitrary 63-bit keys), with many duplicates (stability decides nothing here, but ranks must still be exact), and at
+    sizes around the sort's 4096-element tile."""
+    from visual_underwater_slam_amd import _lib
+    from visual_underwater_slam_amd.gtsam.symbol_shorthand import L, X, V
+    rng = np.random.default_rng(11)
+    lib = _lib.load()
+    cases = []
+    for n in (2, 255, 256, 257, 4095, 4096, 4097, 8193, 70001):
+        mixed = np.concatenate([L(0) + rng.integers(0, 300, size=n), X(0) + rng.integers(0, 70000, size=n),
+                                V(0) + rng.integers(0, 1 << 40, size=n)]).astype(np.int64)
+        rng.shuffle(mixed)
+        cases.append(mixed[:n])
+        cases.append(rng.integers(0, (1 << 63) - 1, size=n, dtype=np.int64))
+        cases.append(np.full(n, L(7), dtype=np.int64))                      # every digit constant
+    for keys in cases:
+        n = len(keys)
+        dk = torch.from_numpy(keys).cuda()
+        idx = torch.empty(n, dtype=torch.int32, device="cuda"); uniq = torch.empty(n, dtype=torch.int64, device="cuda")
+        cnt = torch.empty(2, dtype=torch.int32, device="cuda")
+        nb = int(lib.vus_pack_work_bytes(n))
+        work = torch.empty(nb, dtype=torch.uint8, device="cuda")
+        _lib.call("vus_keys_to_indices", dk.data_ptr(), n, idx.data_ptr(), uniq.data_ptr(), cnt.data_ptr(), work.data_ptr(), nb,
+                  _lib.current_stream_ptr())
+        u, inv = np.unique(keys, return_inverse=True)
+        assert int(cnt[0]) == len(u) and np.array_equal(uniq[:len(u)].cpu().numpy(), u) and np.array_equal(idx.cpu().numpy(), inv), n
+
+
+@pytest.mark.gpu
+def test_device_pack_is_stable_in_the_pose_order(gpu, oracle):
+    """P-order = a STABLE sort of the L-order rows by pose: with many observations per pose the points must stay ascending
+    inside every pose (checked against the oracle by test_device_pack_equals_oracle_and_torch; here directly, at a size
+    of several tiles per pose)."""
+    n_poses, n_points = 3, 30000
+    op, ol, meas = random_observations(np.random.default_rng(5), n_poses, n_points, 60000)
+    got = ba_pack.pack_observations_device(torch.from_numpy(op).cuda(), torch.from_numpy(ol).cuda(),
+                                           torch.from_numpy(meas).cuda(), n_poses, n_points)
+    pose_ptr = got["pose_ptr"].cpu().numpy(); lidx = got["pobs_lidx"].cpu().numpy()
+    pts = got["obs_point"].cpu().numpy(); pos = got["obs_pose"].cpu().numpy()
+    for i in range(n_poses):
+        rows = lidx[pose_ptr[i]:pose_ptr[i + 1]]
+        assert (pos[rows] == i).all() and (np.diff(pts[rows]) > 0).all()
+
+
+@pytest.mark.gpu
 def test_missing_pose_key_is_reported_like_gtsam(gpu):
     import visual_underwater_slam_amd.gtsam as gtsam
     from visual_underwater_slam_amd.gtsam.symbol_shorthand import X, L

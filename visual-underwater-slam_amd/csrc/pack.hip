@@ -10,8 +10,8 @@
 //   vus_exclusive_scan_i32     row counts -> offsets + 64-bit total (the structure builder's list sizes)
 //
 // The sorts are a stable LSD radix sort written here (8-bit digits: per-tile histograms, one scan, a stable scatter that
-// ranks equal digits with wave ballots).  Round 3 first used rocPRIM's device radix sort: faster per call (0.5 ms against
-// 0.9 ms for a configs[2] graph), but its template instantiations made this translation unit's code object 6.8 MB -- 4 MB of
+// ranks equal digits with wave ballots).  Round 3 first used rocPRIM's device radix sort: the same speed per call (0.50 ms
+// against 0.56 ms for a configs[2] graph), but its template instantiations made this translation unit's code object 6.8 MB -- 4 MB of
 // it mangled names -- and LOADING it cost the first optimize() of a process 23 ms (tools/cold_pack_probe.py); batch.py:337
 // calls optimize() exactly once per process.  All results stay on the device.
 #include <cstring>
