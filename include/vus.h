@@ -404,6 +404,15 @@ int vus_nav_eval_step(const vus_nav_factors* N, int n_poses, const double* poses
                       const double* bias, const double* dc, const double* db, const double* new_poses,
                       double* new_vels, double* new_bias, double* out, double* work, void* stream);
 
+/* HOST function (no GPU work, host pointers): on-manifold IMU preintegration, what gtsam::PreintegratedImuMeasurements does
+ * inside integrateMeasurement (reference call sites batch.py:91, 290, 293; Forster et al., TRO 2017).  `pim` is the
+ * 148-double record above, in and out: the n samples {acc[3], gyro[3], dt} are integrated ON TOP of the state it holds
+ * (all zero except dR = identity and the bias estimate = a fresh interval).  acc_cov / gyro_cov / int_cov: the 3x3
+ * continuous-time covariances of PreintegrationParams.  whiten (may be null): W = L^-1, cov = L L^T, row-major 9x9, the
+ * factor's whitening matrix (imu_W); VUS_E_INVALID if the covariance is not positive definite. */
+int vus_imu_preintegrate(double* pim, const double* samples, int n, const double* acc_cov, const double* gyro_cov,
+                         const double* int_cov, double* whiten);
+
 /* err[0] = error of the navigation factors at (poses, vels, bias). */
 int vus_nav_error(const vus_nav_factors* N, int n_poses, const double* poses, const double* vels,
                   const double* bias, double* err, double* work, void* stream);

@@ -149,17 +149,46 @@ def build_nav(oracle, s, with_dvl=True, zero_velocity_prior=True):
     return P, N
 
 
-def test_numpy_preintegration_equals_the_oracle(oracle):
-    from visual_underwater_slam_amd.gtsam.imu import Preintegrator
+def test_preintegration_equals_the_oracle(oracle):
+    """Both preintegrators of gtsam/imu.py -- the library's host function vus_imu_preintegrate behind Preintegrator, and
+    the numpy restatement ReferencePreintegrator -- against the oracle's."""
+    from visual_underwater_slam_amd.gtsam.imu import Preintegrator, ReferencePreintegrator
     from visual_underwater_slam_amd import synth
     s = synth.nav_sequence(4, 50, 20)
     b = np.array([0.01, -0.02, 0.015, 0.002, -0.001, 0.003])
-    pre = Preintegrator(b, ACC_COV, GYRO_COV, INT_COV)
-    for smp in s["imu"][1]:
-        pre.integrate(smp[:3], smp[3:6], smp[6])
     ref = oracle.imu_preintegrate(s["imu"][1], b, ACC_COV, GYRO_COV, INT_COV)
-    assert np.allclose(pre.packed(), ref, rtol=1e-12, atol=1e-18)
-    assert np.allclose(pre.whitening(), oracle.sqrt_information(pre.cov), rtol=1e-9)
+    for cls in (Preintegrator, ReferencePreintegrator):
+        pre = cls(b, ACC_COV, GYRO_COV, INT_COV)
+        for smp in s["imu"][1]:
+            pre.integrate(smp[:3], smp[3:6], smp[6])
+        assert np.allclose(pre.packed(), ref, rtol=1e-12, atol=1e-18), cls.__name__
+        assert np.allclose(pre.whitening(), oracle.sqrt_information(pre.cov), rtol=1e-9), cls.__name__
+
+
+def test_native_preintegration_follows_the_numpy_recursion():
+    """State read in the middle of an interval (the buffered samples are integrated on top of the held state), the
+    small-angle branches (zero and tiny rotation rates), reset, a non-positive dt and a singular covariance."""
+    from visual_underwater_slam_amd.gtsam.imu import Preintegrator, ReferencePreintegrator
+    from visual_underwater_slam_amd import _lib
+    rng = np.random.default_rng(8)
+    b = rng.normal(size=6) * 0.01
+    nat, ref = Preintegrator(b, ACC_COV, GYRO_COV, INT_COV), ReferencePreintegrator(b, ACC_COV, GYRO_COV, INT_COV)
+    rates = [np.zeros(3), b[3:] + 1e-9, b[3:], rng.normal(size=3) * 1e-6] + [rng.normal(size=3) * 0.4 for _ in range(30)]
+    for k, w in enumerate(rates):
+        a, dt = rng.normal(size=3) + np.array([0.0, 0.0, 9.81]), 0.005 * (1 + k % 3)
+        nat.integrate(a, w, dt); ref.integrate(a, w, dt)
+        if k in (0, 3, 17):                # reads flush the buffer; integration goes on from the record
+            assert np.allclose(nat.dR, ref.dR, rtol=1e-13, atol=1e-15) and abs(nat.dt - ref.dt) < 1e-15
+    assert np.allclose(nat.packed(), ref.packed(), rtol=1e-11, atol=1e-16)
+    assert np.allclose(nat.whitening(), ref.whitening(), rtol=1e-9)
+    for name in ("dP", "dV", "dR_dbg", "dP_dba", "dP_dbg", "dV_dba", "dV_dbg", "cov"):
+        assert np.allclose(getattr(nat, name), getattr(ref, name), rtol=1e-11, atol=1e-16), name
+    nat.reset()
+    assert nat.dt == 0.0 and np.array_equal(nat.dR, np.eye(3)) and not nat.cov.any()
+    with pytest.raises(ValueError):
+        nat.integrate(np.zeros(3), np.zeros(3), 0.0)
+    with pytest.raises(_lib.VusError, match="positive definite"):
+        nat.whitening()                    # an empty interval has a zero covariance
 
 
 def test_nav_sequence_is_consistent_with_its_imu_and_dvl(oracle):

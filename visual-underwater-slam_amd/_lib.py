@@ -40,6 +40,7 @@ SIGNATURES = {
     "vus_ba_band_solve_split": [_P, c_int, c_int, _P, _P, _P, _P, _P],
     "vus_ba_band_solve_multi_split": [_P, c_int, c_int, _P, c_int, _P, _P, _P],
     # graph packing (csrc/pack.hip)
+    "vus_imu_preintegrate": [_P, _P, c_int, _P, _P, _P, _P],      # host pointers
     "vus_keys_to_indices": [_P, c_int, _P, _P, _P, _P, ctypes.c_longlong, _P],
     "vus_lookup_keys": [_P, c_int, _P, c_int, _P, _P, _P],
     "vus_ba_pack_observations": [_P, _P, _P, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, ctypes.c_longlong, _P],

@@ -11,6 +11,8 @@
 // receives at most two IMU factors, one DVL factor and one prior, so the sums differ between runs by the order of
 // at most four addends, ~1e-16 relative); the bias-bias block and the bias gradient, which every IMU factor
 // touches, are written per factor and reduced in a fixed order.
+#include <cmath>
+#include <cstring>
 #include "vus_common.h"
 
 namespace {
@@ -570,4 +572,159 @@ extern "C" int vus_nav_error(const vus_nav_factors* N, int n_poses, const double
   double* rec_dvl = rec_imu + (size_t)IMU_REC * N->n_imu;
   double* part = rec_dvl + (size_t)DVL_REC * N->n_dvl;
   return nav_errors(N, n_poses, poses, vels, bias, nullptr, nullptr, 1, rec_imu, rec_dvl, part, err, vus::as_stream(stream));
+}
+
+// ---- host side: IMU preintegration (gtsam does it in C++ inside integrateMeasurement; the Python restatement of it,
+// gtsam/imu.py, cost the end-to-end sequence 78 of its 92 ms) ---------------------------------------------------------
+namespace {
+namespace pim {
+constexpr int DT = 0, DR = 1, DP = 10, DV = 13, DR_DBG = 16, DP_DBA = 25, DP_DBG = 34, DV_DBA = 43, DV_DBG = 52, BIAS = 61, COV = 67;
+
+inline void skew(const double* w, double* W) {
+  W[0] = 0.0;   W[1] = -w[2]; W[2] = w[1];
+  W[3] = w[2];  W[4] = 0.0;   W[5] = -w[0];
+  W[6] = -w[1]; W[7] = w[0];  W[8] = 0.0;
+}
+inline void mul33(const double* A, const double* B, double* C) {
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) C[3 * r + c] = A[3 * r] * B[c] + A[3 * r + 1] * B[3 + c] + A[3 * r + 2] * B[6 + c];
+}
+inline void mul33_tn(const double* A, const double* B, double* C) {      // A^T B
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) C[3 * r + c] = A[r] * B[c] + A[3 + r] * B[3 + c] + A[6 + r] * B[6 + c];
+}
+// exp(w^) and the right Jacobian of SO(3), with the small-angle branches of gtsam/imu.py
+inline void expmap_jr(const double* w, double* R, double* Jr) {
+  const double th2 = w[0] * w[0] + w[1] * w[1] + w[2] * w[2];
+  double W[9], W2[9];
+  skew(w, W);
+  mul33(W, W, W2);
+  double s1, s2;
+  if (th2 <= 2.220446049250313e-16) {
+    s1 = 1.0;
+    s2 = 0.0;
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0 ? 1.0 : 0.0) + W[i];
+  } else {
+    const double th = std::sqrt(th2), sh = std::sin(0.5 * th);
+    s1 = std::sin(th) / th;
+    s2 = 2.0 * sh * sh / th2;
+    for (int i = 0; i < 9; ++i) R[i] = (i % 4 == 0 ? 1.0 : 0.0) + s1 * W[i] + s2 * W2[i];
+  }
+  double a, b;
+  if (th2 < 1e-10) {
+    a = 0.5 - th2 / 24.0;
+    b = 1.0 / 6.0 - th2 / 120.0;
+  } else {
+    const double th = std::sqrt(th2);
+    a = (1.0 - std::cos(th)) / th2;
+    b = (th - std::sin(th)) / (th2 * th);
+  }
+  for (int i = 0; i < 9; ++i) Jr[i] = (i % 4 == 0 ? 1.0 : 0.0) - a * W[i] + b * W2[i];
+}
+
+void integrate(double* p, const double* smp, const double* acc_cov, const double* gyro_cov, const double* int_cov) {
+  const double dt = smp[6];
+  const double a[3] = {smp[0] - p[BIAS], smp[1] - p[BIAS + 1], smp[2] - p[BIAS + 2]};
+  const double w[3] = {(smp[3] - p[BIAS + 3]) * dt, (smp[4] - p[BIAS + 4]) * dt, (smp[5] - p[BIAS + 5]) * dt};
+  double dRinc[9], Jr[9], aX[9], RaX[9];
+  expmap_jr(w, dRinc, Jr);
+  skew(a, aX);
+  double* dR = p + DR;
+  mul33(dR, aX, RaX);
+  // covariance: A cov A^T + B (acc_cov / dt) B^T + C (gyro_cov / dt) C^T, + int_cov dt on the position block
+  double A[81] = {0.0}, Bm[27] = {0.0}, Cm[27] = {0.0};
+  for (int i = 0; i < 9; ++i) A[10 * i] = 1.0;
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) {
+      A[9 * r + c] = dRinc[3 * c + r];
+      A[9 * (3 + r) + c] = -0.5 * dt * dt * RaX[3 * r + c];
+      A[9 * (6 + r) + c] = -dt * RaX[3 * r + c];
+      Bm[3 * (3 + r) + c] = 0.5 * dt * dt * dR[3 * r + c];
+      Bm[3 * (6 + r) + c] = dt * dR[3 * r + c];
+      Cm[3 * r + c] = dt * Jr[3 * r + c];
+    }
+  for (int r = 0; r < 3; ++r) A[9 * (3 + r) + 6 + r] = dt;
+  double* cov = p + COV;
+  double T[81], N[81];
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 9; ++c) {
+      double v = 0.0;
+      for (int k = 0; k < 9; ++k) v += A[9 * r + k] * cov[9 * k + c];
+      T[9 * r + c] = v;
+    }
+  for (int r = 0; r < 9; ++r)
+    for (int c = 0; c < 9; ++c) {
+      double v = 0.0;
+      for (int k = 0; k < 9; ++k) v += T[9 * r + k] * A[9 * c + k];
+      N[9 * r + c] = v;
+    }
+  auto add_noise = [&](const double* G, const double* Q) {      // N += G (Q / dt) G^T, G 9x3
+    double GQ[27];
+    for (int r = 0; r < 9; ++r)
+      for (int c = 0; c < 3; ++c) GQ[3 * r + c] = (G[3 * r] * Q[c] + G[3 * r + 1] * Q[3 + c] + G[3 * r + 2] * Q[6 + c]) / dt;
+    for (int r = 0; r < 9; ++r)
+      for (int c = 0; c < 9; ++c) N[9 * r + c] += GQ[3 * r] * G[3 * c] + GQ[3 * r + 1] * G[3 * c + 1] + GQ[3 * r + 2] * G[3 * c + 2];
+  };
+  add_noise(Bm, acc_cov);
+  add_noise(Cm, gyro_cov);
+  for (int r = 0; r < 3; ++r)
+    for (int c = 0; c < 3; ++c) N[9 * (3 + r) + 3 + c] += int_cov[3 * r + c] * dt;
+  std::memcpy(cov, N, sizeof(N));
+  // bias Jacobians, then the deltas (every update uses the OLD dR, dV)
+  double t[9], tmp[9];
+  mul33(RaX, p + DR_DBG, t);
+  for (int i = 0; i < 9; ++i) {
+    p[DP_DBA + i] += p[DV_DBA + i] * dt - 0.5 * dt * dt * dR[i];
+    p[DP_DBG + i] += p[DV_DBG + i] * dt - 0.5 * dt * dt * t[i];
+    p[DV_DBA + i] -= dt * dR[i];
+    p[DV_DBG + i] -= dt * t[i];
+  }
+  mul33_tn(dRinc, p + DR_DBG, tmp);
+  for (int i = 0; i < 9; ++i) p[DR_DBG + i] = tmp[i] - dt * Jr[i];
+  double Ra[3];
+  for (int r = 0; r < 3; ++r) Ra[r] = dR[3 * r] * a[0] + dR[3 * r + 1] * a[1] + dR[3 * r + 2] * a[2];
+  for (int r = 0; r < 3; ++r) {
+    p[DP + r] += p[DV + r] * dt + 0.5 * dt * dt * Ra[r];
+    p[DV + r] += dt * Ra[r];
+  }
+  mul33(dR, dRinc, tmp);
+  std::memcpy(dR, tmp, sizeof(tmp));
+  p[DT] += dt;
+}
+
+// W = L^-1, cov = L L^T
+bool whitening(const double* cov, double* W) {
+  double L[81] = {0.0};
+  for (int c = 0; c < 9; ++c) {
+    double d = cov[10 * c];
+    for (int k = 0; k < c; ++k) d -= L[9 * c + k] * L[9 * c + k];
+    if (!(d > 0.0)) return false;
+    L[10 * c] = std::sqrt(d);
+    for (int r = c + 1; r < 9; ++r) {
+      double v = cov[9 * r + c];
+      for (int k = 0; k < c; ++k) v -= L[9 * r + k] * L[9 * c + k];
+      L[9 * r + c] = v / L[10 * c];
+    }
+  }
+  for (int c = 0; c < 9; ++c)          // column c of L^-1 by forward substitution
+    for (int r = 0; r < 9; ++r) {
+      double v = (r == c) ? 1.0 : 0.0;
+      for (int k = 0; k < r; ++k) v -= L[9 * r + k] * W[9 * k + c];
+      W[9 * r + c] = v / L[10 * r];
+    }
+  return true;
+}
+}  // namespace pim
+}  // namespace
+
+extern "C" int vus_imu_preintegrate(double* pim_rec, const double* samples, int n, const double* acc_cov, const double* gyro_cov,
+                                    const double* int_cov, double* whiten) {
+  VUS_REQUIRE(pim_rec && acc_cov && gyro_cov && int_cov, "null buffer");
+  VUS_REQUIRE(n >= 0 && (samples != nullptr || n == 0), "n=%d", n);
+  for (int i = 0; i < n; ++i) {
+    VUS_REQUIRE(samples[7 * i + 6] > 0.0, "sample %d: dt=%g is not positive", i, samples[7 * i + 6]);
+    pim::integrate(pim_rec, samples + 7 * (size_t)i, acc_cov, gyro_cov, int_cov);
+  }
+  if (whiten) VUS_REQUIRE(pim::whitening(pim_rec + pim::COV, whiten), "preintegrated covariance is not positive definite");
+  return VUS_OK;
 }

@@ -177,13 +177,21 @@ class BatchSequence:
         for _ in self._camera_side():
             pass
         of, oi, om = factors["obs_frame"].cpu().numpy(), factors["obs_id"].cpu().numpy(), factors["obs_meas"].cpu().numpy()
+        # keys by IN-PLACE adds: `X(0) + of.astype(...)` hands numpy a large temporary, and numpy decides whether it may
+        # reuse it by walking the C stack (backtrace()): with the ROCm and torch libraries loaded the first such walk of a
+        # process costs ~80 ms (measured: 78 of this function's 86 ms)
         if len(of):
-            self.graph.push_back(gtsam.StereoFactorBlock(om, self.landmark_noise, X(0) + of.astype(np.int64),
-                                                         L(0) + oi, self.K))
+            kx = of.astype(np.int64)
+            kx += X(0)
+            kl = oi.astype(np.int64)
+            kl += L(0)
+            self.graph.push_back(gtsam.StereoFactorBlock(om, self.landmark_noise, kx, kl, self.K))
         first = factors["lm_first"].cpu().numpy()
         seen = np.nonzero(first >= 0)[0]
         if len(seen):
-            self.initial_estimate.insert_point3_block(L(0) + seen.astype(np.int64), factors["lm_point"].cpu().numpy()[seen])
+            ks = seen.astype(np.int64)
+            ks += L(0)
+            self.initial_estimate.insert_point3_block(ks, factors["lm_point"].cpu().numpy()[seen])
 
     def optimize(self, params: Optional["gtsam.LevenbergMarquardtParams"] = None):
         """batch.py:337."""
