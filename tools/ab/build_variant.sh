@@ -10,7 +10,7 @@ name=$1; flags=$2
 mkdir -p /tmp/tb_$name
 for kind in n t; do
   extra=""; [ $kind = t ] && extra="-DVUS_TIMING"
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function $extra $flags -c ba.hip -o /tmp/tb_$name/ba_$kind.o \
-    && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 vus_common.o frontend.o /tmp/tb_$name/ba_$kind.o structure.o nav.o pack.o -o "$HERE/libvus_${kind}_$name.so" ) &
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950:xnack- -Wno-unused-function $extra $flags -c ba.hip -o /tmp/tb_$name/ba_$kind.o \
+    && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950:xnack- vus_common.o frontend.o /tmp/tb_$name/ba_$kind.o structure.o nav.o pack.o -o "$HERE/libvus_${kind}_$name.so" ) &
 done
 wait

@@ -1687,6 +1687,7 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
   __shared__ double s_x[BS_MAX_RHS][NB];
   __shared__ double s_part[BS_MAX_RHS][PB][NB];
   __shared__ double s_y[2][BS_MAX_RHS][NB];       // solver: y of this panel / of the next one (look-ahead wave)
+  __shared__ double s_inv[NB * LDD];              // solver: the inverted diagonal panel the next step solves with
   __shared__ int s_go, s_go2[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int NP = (n_poses + PB - 1) / PB;
@@ -1713,13 +1714,6 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
   CB_LOAD_ROWS(NP - 1);
   if (g == 0) {
     // ---- solver ----
-    double Lp[NB];
-    double dinv = 1.0;
-    if (wave < n_rhs) {
-      const int k0 = PB * (NP - 1);
-      if (inverted) cb_load_inv(Sb, band, k0, 6 * min(PB, n_poses - k0), lane, Lp);
-      else cb_load_diag(Sb, band, k0, 6 * min(PB, n_poses - k0), lane, Lp, dinv);
-    }
     // Two of the step's round trips to the coherence point are taken off its chain: while the solving waves work on
     // panel p, the last wave (idle otherwise: the products use threads < 8 * 48) waits for the flags of every
     // workgroup that adds to y of panel p-1 and loads that y into LDS.  (Those flags only depend on x of panels
@@ -1734,6 +1728,127 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
       if (lane == 0) s_go2[0] = 1;
     }
     __syncthreads();
+    if (inverted) {
+      // ---- pipelined sweep (diagonal panels inverted in place) ----
+      // The inverted panel of step s+1 travels while step s runs: threads < 8 * 48 request its 2304 elements (six each)
+      // at the END of step s-1, park them in LDS at the end of step s, and the solving waves read their column from LDS
+      // at the start of step s+1.  Loaded into registers after the step's flag, as before, the 48 loads were a memory
+      // round trip on the chain: 4.2 k of the step's 6.9 k cycles (tools/backsolve_timing.py).  The step's last barrier
+      // is LDS-only, so that the requests stay in flight across it.
+      const int pc = tid % NB, prg = tid / NB;           // prefetch task: column pc, rows prg + 8 i
+      double pre[6];
+      // the thread's six offsets inside a panel, computed once (cb_inv = panel base + column part + row part)
+      int rel[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i)
+        rel[i] = (int)(bandidx::cb_inv_base(band, 0, pc) + bandidx::cb_inv_delta(band, prg < PB ? prg + 8 * i : 0));
+      auto request = [&](int pp) {                      // panel pp's inverse -> pre (masked elements: a safe address)
+        const int k0p = PB * pp, nbp = 6 * min(PB, n_poses - k0p);
+        const double* base = Sb + bandidx::cb_inv_safe(band, k0p);       // the panel's first element
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pre[i] = base[(prg < PB && bandidx::cb_inv_stored(nbp, pc, prg + 8 * i)) ? rel[i] : 0];
+      };
+      auto park = [&](int pp) {      // after the step's first barrier: the solving waves have their columns in registers
+        const int k0p = PB * pp, nbp = 6 * min(PB, n_poses - k0p);
+        if (prg < PB) {
+#pragma unroll
+          for (int i = 0; i < 6; ++i) {
+            const int r = prg + 8 * i;
+            s_inv[r * LDD + pc] = bandidx::cb_inv_stored(nbp, pc, r) ? pre[i] : 0.0;
+          }
+        }
+      };
+      request(NP - 1);
+      park(NP - 1);
+      if (NP > 1) request(NP - 2);
+      __syncthreads();
+      for (int s = 0; s < NP; ++s) {
+        const int p = NP - 1 - s, k0 = PB * p;
+        const int nb = 6 * min(PB, n_poses - k0);
+        const int cur = s & 1;
+        if (!s_go2[cur]) break;
+#ifdef VUS_TIMING
+        const bool bm_on = s == 40 && wg == 0 && NP > 60;
+#define VUS_BM(k) do { if (bm_on && tid == 0) s_wtm[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define VUS_BM(k)
+#endif
+        VUS_BM(0);
+        if (wave < n_rhs) {
+          double* yq = yv + (size_t)wave * ystride;
+          double yr = lane < NB ? s_y[cur][wave][lane] : 0.0;
+          const double* invc = &s_inv[lane < NB ? lane : 0];
+          double Lc[NB];
+#pragma unroll
+          for (int r = 0; r < NB; ++r) Lc[r] = invc[r * LDD];
+          if (s > 0 && lane < NB) {       // what x of the panel below added (its eight block rows' products)
+#pragma unroll
+            for (int k2 = 0; k2 < PB; ++k2) yr -= s_part[wave][k2][lane];
+          }
+          // x_c = sum_r (L_pp^-1)[r][c] y'_r: four independent chains of multiply-adds
+          double z4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int r = 0; r < NB; ++r) z4[r & 3] += Lc[r] * bcast_lane(yr, r);
+          const double z = (z4[0] + z4[1]) + (z4[2] + z4[3]);
+          VUS_BM(1);
+          if (lane < nb) {
+            __hip_atomic_store(&yq[6 * k0 + lane], z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_x[wave][lane] = z;
+          } else if (lane < NB) {
+            s_x[wave][lane] = 0.0;
+          }
+          cb_drain();
+          VUS_BM(2);
+        }
+        if (wave == LA && p > 0) {   // look-ahead (after its own solve when all eight waves carry a right-hand side)
+          bool ok = true;
+          for (int g0 = 1; g0 < n_groups && ok; g0 += 64) {
+            const int gg = g0 + lane;
+            if (gg < n_groups && s + 1 - gg > 0) ok = cb_wait(F + 2 + gg, s + 1 - gg, abort_flag);
+            ok = __all(ok);
+          }
+#ifdef VUS_TIMING
+          if (bm_on && lane == 0) s_wtm[6] = __builtin_amdgcn_s_memtime();
+#endif
+          if (ok) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            for (int t = lane; t < NB * n_rhs; t += 64) {     // a full panel: NB rows
+              const int q = t / NB, r = t - NB * q;
+              s_y[cur ^ 1][q][r] = __hip_atomic_load(&yv[(size_t)q * ystride + 6 * (k0 - PB) + r], __ATOMIC_RELAXED,
+                                                     __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+          if (lane == 0) s_go2[cur ^ 1] = ok;
+#ifdef VUS_TIMING
+          if (bm_on && lane == 0) s_wtm[7] = __builtin_amdgcn_s_memtime();
+#endif
+        }
+        __syncthreads();
+        VUS_BM(3);
+        if (tid == 0) __hip_atomic_store(F, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (p > 0) {   // contribution of x_p to the panel right above (kept in LDS, subtracted at the next step)
+          CB_PARTIAL_DOTS();
+          VUS_BM(4);
+          park(p - 1);                          // requested a step ago
+          if (p > 1) request(p - 2);
+          CB_LOAD_ROWS(p - 1);
+        }
+        lds_barrier();                          // the requests above stay in flight
+#ifdef VUS_TIMING
+        if (bm_on && tid == 0) {
+          s_wtm[5] = __builtin_amdgcn_s_memtime();
+          for (int k = 0; k < 8; ++k) g_wtm[k] = s_wtm[k];
+        }
+#endif
+      }
+    } else {
+    // ---- narrow bands (< 7 poses): the factor itself, 48-step substitution, operands loaded after the step's flag ----
+    double Lp[NB];
+    double dinv = 1.0;
+    if (wave < n_rhs) {
+      const int k0 = PB * (NP - 1);
+      cb_load_diag(Sb, band, k0, 6 * min(PB, n_poses - k0), lane, Lp, dinv);
+    }
     for (int s = 0; s < NP; ++s) {
       const int p = NP - 1 - s, k0 = PB * p;
       const int nb = 6 * min(PB, n_poses - k0);
@@ -1793,6 +1908,7 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
         CB_LOAD_ROWS(p - 1);
       }
       __syncthreads();
+    }
     }
   } else {
     // ---- row group gg: panels NP-1 .. gg+1 contribute to panels NP-gg-2 .. 0 ----
