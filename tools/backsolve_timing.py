@@ -18,9 +18,9 @@ lib = _lib.load()
 rows = []
 for it in range(5):
     sv.linearize(p0, x0); sv.schur(1e-5); sv.band_solve(); torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 32)()
     assert lib.vus_debug_read_wtm(buf) == 0
-    t = np.array(list(buf)[:8], dtype=np.int64)
+    t = np.array(list(buf)[16:28], dtype=np.int64)
     rows.append(t - t[0])
 med = np.median(np.array(rows), axis=0).astype(int).tolist()
-print(json.dumps({"marks_from_step_start": dict(zip(["start", "solved", "drained", "after_barrier_1", "products_done", "end_of_step", "lookahead_flags_seen", "lookahead_y_loaded"], med))}))
+print(json.dumps({"marks_from_step_start": dict(zip(["start", "solved", "drained", "after_barrier_1", "products_done", "end_of_step", "lookahead_flags_seen", "lookahead_y_loaded", "flag_stored", "parked", "rows_requested", "inverse_requested"], med))}))

@@ -21,7 +21,7 @@ rows = []
 for it in range(4):
     sv.optimize(p0, x0)
     torch.cuda.synchronize()
-    buf = (ctypes.c_ulonglong * 16)()
+    buf = (ctypes.c_ulonglong * 32)()
     assert lib.vus_debug_read_wtm(buf) == 0
     t = np.array(list(buf), dtype=np.int64)
     rows.append(np.diff(t[:12]))

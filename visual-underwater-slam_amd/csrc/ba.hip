@@ -744,7 +744,7 @@ __device__ __forceinline__ void panel_update(double (&blk)[6], const double (&xr
 // a device array and printed once after the last step, so that the marks cost thread 0 a scalar load and a store and
 // nothing else (a printf inside the loop costs the whole kernel registers and shifts every number)
 #ifdef VUS_TIMING
-__device__ unsigned long long g_wtm[16];
+__device__ unsigned long long g_wtm[32];      // [0, 16): window kernel; [16, 32): back-substitution
 __shared__ unsigned long long s_wtm[16];       // marks go to LDS (a global store per mark would stall thread 0's wave at the next reuse of its registers)
 #define VUS_WM(k) do { if (vus_wm_on && threadIdx.x == 0) s_wtm[k] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -1745,8 +1745,12 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
       auto request = [&](int pp) {                      // panel pp's inverse -> pre (masked elements: a safe address)
         const int k0p = PB * pp, nbp = 6 * min(PB, n_poses - k0p);
         const double* base = Sb + bandidx::cb_inv_safe(band, k0p);       // the panel's first element
+        const double* pa[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) pre[i] = base[(prg < PB && bandidx::cb_inv_stored(nbp, pc, prg + 8 * i)) ? rel[i] : 0];
+        for (int i = 0; i < 6; ++i) pa[i] = base + ((prg < PB && bandidx::cb_inv_stored(nbp, pc, prg + 8 * i)) ? rel[i] : 0);
+        __builtin_amdgcn_sched_barrier(0);              // every address first, then the loads back to back
+#pragma unroll
+        for (int i = 0; i < 6; ++i) pre[i] = *pa[i];
       };
       auto park = [&](int pp) {      // after the step's first barrier: the solving waves have their columns in registers
         const int k0p = PB * pp, nbp = 6 * min(PB, n_poses - k0p);
@@ -1769,7 +1773,7 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
         if (!s_go2[cur]) break;
 #ifdef VUS_TIMING
         const bool bm_on = s == 40 && wg == 0 && NP > 60;
-#define VUS_BM(k) do { if (bm_on && tid == 0) s_wtm[k] = __builtin_amdgcn_s_memtime(); } while (0)
+#define VUS_BM(k) do { if (bm_on && tid == 0) s_wtm[k] = __builtin_amdgcn_s_memtime(); } while (0)      /* marks land in g_wtm[16 + k] */
 #else
 #define VUS_BM(k)
 #endif
@@ -1825,19 +1829,25 @@ __global__ __launch_bounds__(CB_THREADS) void chol_backsolve_kernel(BandSet S, i
         }
         __syncthreads();
         VUS_BM(3);
-        if (tid == 0) __hip_atomic_store(F, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the step's flag is raised by a lane of the look-ahead wave: the waves that go on to the products below wait for
+        // their block rows with s_waitcnt vmcnt(0), which would also wait for this store's round trip (1 k cycles)
+        if (tid == 64 * LA) __hip_atomic_store(F, s + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (p > 0) {   // contribution of x_p to the panel right above (kept in LDS, subtracted at the next step)
+          VUS_BM(8);
           CB_PARTIAL_DOTS();
           VUS_BM(4);
           park(p - 1);                          // requested a step ago
-          if (p > 1) request(p - 2);
+          VUS_BM(9);
           CB_LOAD_ROWS(p - 1);
+          VUS_BM(10);
+          if (p > 1) request(p - 2);
+          VUS_BM(11);
         }
         lds_barrier();                          // the requests above stay in flight
 #ifdef VUS_TIMING
         if (bm_on && tid == 0) {
           s_wtm[5] = __builtin_amdgcn_s_memtime();
-          for (int k = 0; k < 8; ++k) g_wtm[k] = s_wtm[k];
+          for (int k = 0; k < 12; ++k) g_wtm[16 + k] = s_wtm[k];
         }
 #endif
       }
@@ -3329,7 +3339,7 @@ extern "C" int vus_ba_eval_step(const vus_ba_problem* P, const double* poses, co
 
 #ifdef VUS_TIMING
 // timing builds only (tools/win_timing.py): the s_memtime marks of the window kernel's critical workgroup, panel 41
-extern "C" int vus_debug_read_wtm(unsigned long long* out16) {
-  return hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wtm), sizeof(g_wtm)) == hipSuccess ? 0 : -1;
+extern "C" int vus_debug_read_wtm(unsigned long long* out32) {
+  return hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_wtm), sizeof(g_wtm)) == hipSuccess ? 0 : -1;
 }
 #endif
