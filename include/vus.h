@@ -40,6 +40,10 @@ extern "C" {
 
 int vus_abi_version(void);
 const char* vus_last_error(void);
+/* The target ID the library's code objects were built for, e.g. "gfx950:xnack-" (csrc/Makefile, OFFLOAD).  A device
+ * whose target ID does not match runs none of them ("no kernel image is available"): the Python binding compares this
+ * string with the device's gcnArchName before the first launch and says what to rebuild. */
+const char* vus_build_target(void);
 
 /* ------------------------------------------------------------------------------------------
  * Stereo ORB front-end.  Images are uint8, row-major [n_img, H, pitch] (pitch >= W bytes).
@@ -369,6 +373,17 @@ int vus_ba_band_solve_multi_split(double* Sband, int n_nodes, int band, double* 
 #define VUS_TUNE_BAND_MODE 0
 #define VUS_TUNE_CB_MAX_WG 1
 #define VUS_TUNE_LAST_BAND_MODE 2   /* read-only (vus_ba_get_tuning): how the most recent factorisation was issued, 0..3 */
+#define VUS_TUNE_WIN_FAULT 3        /* tests only: 1 makes one workgroup of the window kernel exit at once, as a workgroup
+                                       that never became resident would; the launch then ends in VUS_STATUS_WINDOW_EXPIRED */
+/* Negative values of a band solve's status word (every inter-workgroup wait is bounded; none of them is a hang):
+ *   VUS_STATUS_WAIT_EXPIRED    a wait of the cooperative back-substitution expired;
+ *   VUS_STATUS_WINDOW_EXPIRED  a wait of the persistent window kernel (mode 3) expired: its flag protocol needs every
+ *                              workgroup of the launch resident at once, which other work on the device (another
+ *                              process or stream holding CUs) can prevent.  The band is spoilt; a caller redoes the
+ *                              Schur step and solves with VUS_TUNE_BAND_MODE 2 (launch pairs: no residency demand) --
+ *                              ba.py does exactly that, once, and keeps the window kernel off afterwards. */
+#define VUS_STATUS_WAIT_EXPIRED (-1)
+#define VUS_STATUS_WINDOW_EXPIRED (-3)
 int vus_ba_set_tuning(int knob, int value);
 int vus_ba_get_tuning(int knob);
 

@@ -44,9 +44,11 @@ def band_tuning():
     """Set the band solve's tuning knobs for one test (vus_ba_set_tuning) and restore them afterwards."""
     from visual_underwater_slam_amd import _lib
     lib = _lib.load()
-    before = {k: lib.vus_ba_get_tuning(k) for k in (_lib.TUNE_BAND_MODE, _lib.TUNE_CB_MAX_WG)}
+    before = {k: lib.vus_ba_get_tuning(k) for k in (_lib.TUNE_BAND_MODE, _lib.TUNE_CB_MAX_WG, _lib.TUNE_WIN_FAULT)}
 
-    def set_(band_mode=None, cb_max_wg=None):
+    def set_(band_mode=None, cb_max_wg=None, win_fault=None):
+        if win_fault is not None:
+            _lib.call("vus_ba_set_tuning", _lib.TUNE_WIN_FAULT, int(win_fault))
         if band_mode is not None:
             _lib.call("vus_ba_set_tuning", _lib.TUNE_BAND_MODE, int(band_mode))
         if cb_max_wg is not None:

@@ -5,7 +5,7 @@ import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # entry points that return something else than a status code (bound by hand in _lib.load) or have no device work
-HOST_ONLY = ("vus_abi_version", "vus_last_error", "vus_ba_work_doubles", "vus_nav_work_doubles",
+HOST_ONLY = ("vus_abi_version", "vus_last_error", "vus_build_target", "vus_ba_work_doubles", "vus_nav_work_doubles",
              "vus_ba_band_solve_work_doubles", "vus_ba_get_tuning", "vus_pack_work_bytes", "vus_imu_preintegrate")
 
 
@@ -33,6 +33,16 @@ def test_hip_library_exports_every_declared_symbol():
     for name in _declared():
         if name not in HOST_ONLY:
             assert name in L.SIGNATURES, f"{name} missing from _lib.SIGNATURES"
+
+
+def test_build_target_is_reported_and_checked_against_the_device_name():
+    import visual_underwater_slam_amd._lib as L
+    lib = L.load()
+    assert lib.vus_build_target().decode().startswith("gfx950")
+    assert L.target_mismatch("gfx950:xnack-", "gfx950:sramecc+:xnack-") is None
+    assert L.target_mismatch("gfx950", "gfx950:sramecc+:xnack+") is None               # a generic object runs anywhere
+    assert "OFFLOAD=--offload-arch=gfx950" in L.target_mismatch("gfx950:xnack-", "gfx950:sramecc+:xnack+")
+    assert "gfx942" in L.target_mismatch("gfx950:xnack-", "gfx942:sramecc+:xnack-")
 
 
 def test_oracle_exports_cpu_twins(oracle):

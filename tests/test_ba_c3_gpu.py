@@ -1,5 +1,5 @@
-"""BASELINE.json configs[2] at FULL size through the HIP path: 2000 keyframes x 50k landmarks (48,299 observed),
-1.93 M stereo factors, band 224 pose blocks (28 cooperating row groups in the back-substitution).
+"""BASELINE.json configs[2] at FULL size through the HIP path: 2000 keyframes, 50,238 OBSERVED landmarks, 2,000,201 stereo
+factors (synth.CONFIGS2_BA), band 224 pose blocks (28 cooperating row groups in the back-substitution).
 
 The scalar oracle cannot run the whole problem in test time, so parity at this size is established on
 SUB-PROBLEMS whose oracle results equal the corresponding slices of the full problem exactly:
@@ -17,7 +17,7 @@ from visual_underwater_slam_amd import synth, ba_pack
 
 pytestmark = pytest.mark.gpu
 
-N_KF, N_LM, OBS = 2000, 50000, 1000
+N_KF, N_LM, OBS = synth.CONFIGS2_BA
 
 
 def relerr(a, b):
@@ -49,7 +49,7 @@ def sub_problem(oracle, s, mask):
 
 def test_c3_has_the_baseline_size(c3):
     s, prob, sv = c3
-    assert prob.n_poses == 2000 and 45000 < prob.n_points <= 50000 and 1.8e6 < prob.n_obs <= 2.0e6
+    assert prob.n_poses == 2000 and prob.n_points == 50238 and prob.n_obs == 2000201          # >= 50 k observed, >= 2.0 M
     assert prob.band >= 200 and prob.st["n_pairs"] > 5e7
 
 

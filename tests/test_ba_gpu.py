@@ -371,6 +371,38 @@ def test_two_sided_solve_inside_the_lm_gives_the_one_sided_result(gpu, oracle):
     assert relerr(points2.cpu().numpy(), points1.cpu().numpy()) < 1e-7
 
 
+def test_window_kernel_that_cannot_keep_its_workgroups_resident_falls_back_to_launch_pairs(gpu, oracle, band_tuning):
+    """chol_window_kernel's flag protocol needs its whole grid resident; when something else holds CUs a
+    workgroup never starts, the bounded waits expire (milliseconds, not seconds) and the status word says
+    VUS_STATUS_WINDOW_EXPIRED.  optimize() then redoes the trial with the launch-pair mode, latches it, warns -- and
+    gives the result of an undisturbed run.  The fault is injected (VUS_TUNE_WIN_FAULT: one workgroup returns at once)."""
+    import time
+    import warnings
+    from visual_underwater_slam_amd import _lib
+    lib = _lib.load()
+    band_tuning(band_mode=-1, win_fault=0)
+    s, prob, sv, P = setup(oracle, 300, 6000, 300, line_len=8)       # band 39 pose blocks
+    p0, x0 = torch.from_numpy(s["poses_init"]).cuda(), torch.from_numpy(s["points_init"]).cuda()
+    poses_a, points_a, rep_a = sv.optimize(p0, x0)
+    assert lib.vus_ba_get_tuning(_lib.TUNE_LAST_BAND_MODE) == 3      # the window kernel is the automatic choice here
+    band_tuning(win_fault=1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        t0 = time.perf_counter()
+        poses_b, points_b, rep_b = sv.optimize(p0, x0)
+        dt = time.perf_counter() - t0
+    assert any("launch-pair" in str(x.message) for x in w) and sv.window_fallbacks == 1
+    assert lib.vus_ba_get_tuning(_lib.TUNE_BAND_MODE) == 2 and lib.vus_ba_get_tuning(_lib.TUNE_LAST_BAND_MODE) != 3
+    assert dt < 2.0                                                  # the expired waits cost milliseconds
+    assert (rep_a.outer, rep_a.tries, rep_a.status) == (rep_b.outer, rep_b.tries, rep_b.status)
+    assert np.allclose(rep_a.err_hist, rep_b.err_hist, rtol=1e-9)
+    assert relerr(poses_b.cpu().numpy(), poses_a.cpu().numpy()) < 1e-8
+    # a mode the caller FORCED is not overridden: the expired wait is raised
+    band_tuning(band_mode=3)
+    with pytest.raises(RuntimeError, match="timed out"):
+        sv.optimize(p0, x0)
+
+
 def test_one_sided_band_solve_with_the_two_launch_panel_step(gpu, band_tuning):
     """The TRSM + SYRK launch pair (normally used by the two-sided solve) driving a whole one-sided factorisation,
     including bands narrower than a panel, band 0 and shrinking windows at the end of the matrix."""

@@ -310,6 +310,43 @@ def test_full_frontend_pipeline_matches_oracle_chain(gpu, oracle):
     assert len(ids0 & {f_.id for f_ in msgs[1].features}) > 50   # tracks persist across frames
 
 
+def test_configs1_launch_shape_1000_frames_matches_oracle_at_both_ends_and_the_middle(gpu, oracle):
+    """BASELINE.json configs[1] exactly as bench.py runs it -- ONE StereoOrbFrontend.process() over the resident
+    1000-frame 1280x720 stream (grid.z = 2000 images, 1.84 GB of pixels, 2000 x 32768 candidate slots) -- compared with
+    the oracle on frames 0, 499 and 999 (and their temporal successors): keypoints, descriptors, stereo and temporal
+    matches bit for bit.  The timed launch shape, not a 3-frame stand-in."""
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    F, H, W = 1000, 720, 1280
+    cv = synth.canvas(torch, "cuda")
+    stream = torch.empty((F, 2, H, W), dtype=torch.uint8, device="cuda")
+    for s0 in range(0, F, 8):
+        stream[s0:s0 + 8] = synth.stereo_frames(s0, min(8, F - s0), H, W, xp=torch, device="cuda", canvas_arr=cv)
+    fe = StereoOrbFrontend(H, W, max_frames=F, params=ImageProcessorParams())
+    res = fe.process(stream)
+    torch.cuda.synchronize()
+    p = fe.p
+    assert int(res.kp_count.min()) == p.max_features                  # every image yields its 2000 keypoints
+    for t in (0, 499, 998):                                            # frames t, t + 1: 0/1, 499/500, 998/999
+        img = stream[t:t + 2].cpu().numpy()
+        assert np.array_equal(img, synth.stereo_frames(t, 2))          # the torch-generated stream == the numpy one
+        flat = img.reshape(4, H, W)
+        kp, kc, blur, desc, ang = _pipeline_oracle(oracle, flat, p.max_features)
+        sl = slice(2 * t, 2 * t + 4)
+        assert np.array_equal(res.kp_count[sl].cpu().numpy(), kc)
+        assert np.array_equal(_u32(res.kp_keys[sl]), kp)
+        assert np.array_equal(res.desc[sl].cpu().numpy().view(np.uint64), desc)
+        assert np.array_equal(res.angle[sl].cpu().numpy(), ang)
+        f = np.arange(2, dtype=np.int32)
+        sidx, sdist = oracle.hamming_match(desc, kp, kc, W, 2 * f, 2 * f + 1, p.stereo_threshold,
+                                           p.min_disparity, p.max_disparity, p.stereo_max_distance)
+        tidx, tdist = oracle.hamming_match(desc, kp, kc, W, 2 * f[:1], 2 * f[:1] + 2, -1, 0, 0, p.track_max_distance)
+        assert np.array_equal(res.stereo_idx[t:t + 2].cpu().numpy(), sidx)
+        assert np.array_equal(res.stereo_dist[t:t + 2].cpu().numpy(), sdist)
+        assert np.array_equal(res.track_idx[t:t + 1].cpu().numpy(), tidx)
+        assert np.array_equal(res.track_dist[t:t + 1].cpu().numpy(), tdist)
+        assert (sidx >= 0).sum() > 1500 and (tidx >= 0).sum() > 800
+
+
 def test_track_ids_matches_oracle_and_feeds_get_landmarks(gpu, oracle):
     """vus_track_ids on the GPU == oracle; its features go through vus_triangulate (batch.py:144-176)."""
     from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams, triangulate

@@ -287,10 +287,14 @@ def test_values_store_single_insertions_column_wise():
     assert keys.tolist() == [X(i) for i in range(7)] and tab[3, 9:].tolist() == [3.0, 6.0, 9.0]
     with pytest.raises(RuntimeError, match="already exists"):
         v.insert(L(5), np.zeros(3))
-    with pytest.raises(RuntimeError, match="does not hold what atPose3 asks for"):
+    with pytest.raises(RuntimeError, match="does not hold what atPose3 asks for") as kept:
         v.pose3_block([L(5)])
-    with pytest.raises(RuntimeError, match="does not exist"):
+    with pytest.raises(RuntimeError, match="does not exist") as kept2:
         v.point3_block([L(5), L(9999)])
+    # the exceptions (and their tracebacks, with every frame's locals) are still alive here: no view of the growing
+    # columns may be among them, or the next insert could not resize its store (BufferError)
+    v.insert(L(500), np.ones(3)); v.insert(X(7), Pose3()); v.erase(L(500)); v.erase(X(7))
+    assert kept.value is not None and kept2.value is not None
     w = Values(v)                                                     # copies do not share storage
     w.update(L(5), [9.0, 9.0, 9.0]); w.erase(L(6)); w.insert(L(6), [1.0, 1.0, 1.0]); w.erase(X(6))
     assert np.array_equal(v.atPoint3(L(5)), pts[5]) and np.array_equal(v.atPoint3(L(6)), pts[6]) and v.exists(X(6))

@@ -7,10 +7,16 @@ set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
 cd "$HERE/../../visual-underwater-slam_amd/csrc"
 name=$1; flags=$2
+OFFLOAD=$(make -s print-offload)          # the one place that names the target: csrc/Makefile
 mkdir -p /tmp/tb_$name
+rm -f "$HERE/libvus_n_$name.so" "$HERE/libvus_t_$name.so"     # a failed build must not leave an older binary to be timed
+pids=()
 for kind in n t; do
   extra=""; [ $kind = t ] && extra="-DVUS_TIMING"
-  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950:xnack- -Wno-unused-function $extra $flags -c ba.hip -o /tmp/tb_$name/ba_$kind.o \
-    && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950:xnack- vus_common.o frontend.o /tmp/tb_$name/ba_$kind.o structure.o nav.o pack.o -o "$HERE/libvus_${kind}_$name.so" ) &
+  ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC $OFFLOAD -Wno-unused-function $extra $flags -c ba.hip -o /tmp/tb_$name/ba_$kind.o \
+    && /opt/rocm/bin/hipcc -shared -fPIC $OFFLOAD vus_common.o frontend.o /tmp/tb_$name/ba_$kind.o structure.o nav.o pack.o -o "$HERE/libvus_${kind}_$name.so" ) &
+  pids+=($!)
 done
-wait
+for pid in "${pids[@]}"; do
+  wait "$pid" || { echo "build_variant.sh: building variant '$name' failed" >&2; exit 1; }
+done

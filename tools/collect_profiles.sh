@@ -42,7 +42,8 @@ python3 $ROOT/tools/band_modes_probe.py 2 3 2>/dev/null | grep '^{' > $OUT/band_
 python3 $ROOT/tools/cold_phases.py 2>/dev/null | grep '^{' > $OUT/cold_phases_${TAG}.txt || true
 # 8. where a panel step of the window kernel's critical workgroup goes: s_memtime marks of a -DVUS_TIMING build of the library
 CS=$ROOT/visual-underwater-slam_amd/csrc
-mkdir -p /tmp/tb && (cd $CS && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950:xnack- -Wno-unused-function -DVUS_TIMING -c ba.hip -o /tmp/tb/ba_t.o 2>/dev/null \
-  && /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950:xnack- vus_common.o frontend.o /tmp/tb/ba_t.o structure.o nav.o pack.o -o /tmp/tb/libvus_timing.so) \
+OFFLOAD=$(make -s -C $CS print-offload)
+mkdir -p /tmp/tb && (cd $CS && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC $OFFLOAD -Wno-unused-function -DVUS_TIMING -c ba.hip -o /tmp/tb/ba_t.o 2>/dev/null \
+  && /opt/rocm/bin/hipcc -shared -fPIC $OFFLOAD vus_common.o frontend.o /tmp/tb/ba_t.o structure.o nav.o pack.o -o /tmp/tb/libvus_timing.so) \
   && VUS_HIP_LIB=/tmp/tb/libvus_timing.so python3 $ROOT/tools/win_timing.py 2>/dev/null | grep '^{' > $OUT/window_step_cycles_${TAG}.txt || true
 ls -la $OUT

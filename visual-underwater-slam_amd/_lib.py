@@ -55,7 +55,8 @@ SIGNATURES = {
     "vus_ba_set_tuning": [c_int, c_int],
 }
 
-TUNE_BAND_MODE, TUNE_CB_MAX_WG, TUNE_LAST_BAND_MODE = 0, 1, 2       # VUS_TUNE_* of include/vus.h
+TUNE_BAND_MODE, TUNE_CB_MAX_WG, TUNE_LAST_BAND_MODE, TUNE_WIN_FAULT = 0, 1, 2, 3       # VUS_TUNE_* of include/vus.h
+STATUS_WAIT_EXPIRED, STATUS_WINDOW_EXPIRED = -1, -3
 
 
 class VusError(RuntimeError):
@@ -80,6 +81,7 @@ def load():
     lib = ctypes.CDLL(LIB_PATH)
     lib.vus_abi_version.restype = c_int
     lib.vus_last_error.restype = c_char_p
+    lib.vus_build_target.restype = c_char_p
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree
         fn.argtypes = argtypes
@@ -115,8 +117,34 @@ def current_stream_ptr():
     return torch.cuda.current_stream().cuda_stream
 
 
+def target_mismatch(built: str, device_arch: str):
+    """None if code objects built for target ID `built` (e.g. "gfx950:xnack-") load on a device whose gcnArchName is
+    `device_arch` (e.g. "gfx950:sramecc+:xnack-"); else the sentence to raise.  A feature the build pins (":xnack-")
+    must be the device's setting; a feature it leaves open matches any."""
+    b, d = built.split(":"), device_arch.split(":")
+    if b[0] != d[0]:
+        return (f"libvus_hip.so was built for {built} but the device is {device_arch}: this library targets MI355X "
+                f"(gfx950) only")
+    for feat in b[1:]:
+        if feat not in d[1:]:
+            return (f"libvus_hip.so was built for target ID {built} but the device runs {device_arch}: no code object "
+                    f"matches (every launch would fail with 'no kernel image is available'). Rebuild with "
+                    f"`make -C visual-underwater-slam_amd/csrc clean all OFFLOAD=--offload-arch={b[0]}`")
+    return None
+
+
+_target_checked = False
+
+
 def require_gpu():
+    global _target_checked
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("visual_underwater_slam_amd needs an MI355X (HIP device); no GPU is visible "
                            "and there is deliberately no CPU fallback.")
+    if not _target_checked:
+        arch = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")
+        why = target_mismatch(load().vus_build_target().decode(), arch) if arch else None
+        if why:
+            raise RuntimeError(why)
+        _target_checked = True

@@ -240,6 +240,23 @@ class StereoBASolver:
             _lib.call("vus_ba_band_solve", p(self.Sband), self.P.n_nodes, self.P.band, p(self.gs), p(self.dp),
                       p(self.status), _lib.current_stream_ptr())
 
+    def _window_expired(self, status) -> bool:
+        """True if the trial should be redone: the persistent window kernel (band mode 3) gave up a bounded wait
+        (VUS_STATUS_WINDOW_EXPIRED) -- its flag protocol needs every workgroup of its launch resident at once, and other
+        work on the device (another rank or process on this GPU, a kernel of another stream holding CUs) can prevent
+        that.  The launch-pair mode has no such demand: it is latched for the rest of the process (vus_ba_set_tuning is
+        process-wide) and the caller redoes Schur + solve.  Every rank of a sharded solve sees the same status word and
+        takes the same branch.  An expired wait under a mode the caller FORCED, or a second failure, is raised."""
+        lib = _lib.load()
+        if status != _lib.STATUS_WINDOW_EXPIRED or lib.vus_ba_get_tuning(_lib.TUNE_BAND_MODE) >= 0:
+            return False
+        import warnings
+        warnings.warn("vus band solve: the persistent window kernel could not keep its workgroups resident (is other work "
+                      "running on this GPU?); falling back to the launch-pair factorisation for the rest of the process")
+        _lib.call("vus_ba_set_tuning", _lib.TUNE_BAND_MODE, 2)
+        self.window_fallbacks = getattr(self, "window_fallbacks", 0) + 1
+        return True
+
     def backsub(self):
         p = _lib.ptr
         _lib.call("vus_ba_backsub", self._pp(), p(self.W), p(self.Vinv), p(self.gl), p(self.dp), p(self.dl),
@@ -284,6 +301,8 @@ class StereoBASolver:
                 rec = self._trial.cpu()                           # the trial's ONE blocking read
                 sc, status = rec[:4], int(rec[4:].view(torch.int32)[0])
                 if status < 0:
+                    if self._window_expired(status):              # the band is spoilt: redo this trial launch by launch
+                        continue
                     raise RuntimeError("vus_ba_band_solve: the cooperative back-substitution timed out (status %d)" % status)
                 rep.tries += 1
                 a_lin, a_new = aux.try_lambda(lam) if aux else (0.0, 0.0)
@@ -469,6 +488,8 @@ class NavBASolver(StereoBASolver):
                 rec = self._trial.cpu()                           # stereo scalars + status, then the inertial scalars
                 sc, status, nsc = rec[:4], int(rec[4:].view(torch.int32)[0]), self.nav_scal.cpu()
                 if status < 0:
+                    if self._window_expired(status):
+                        continue
                     raise RuntimeError("vus_ba_band_solve: the cooperative back-substitution timed out (status %d)" % status)
                 rep.tries += 1
                 if lin0 is None:

@@ -29,6 +29,8 @@
 //   backsub      wave / point      dl = -Vinv (gl + sum W^T dp)
 //   retract, eval_points, error_points, reduce_partials
 #include <atomic>
+#include <cerrno>
+#include <cstdio>
 #include <cstdlib>
 #include <memory>
 #include <mutex>
@@ -44,10 +46,25 @@ struct Knobs {
   std::atomic<int> cb_max_wg{0};
   std::atomic<int> last_mode{-1};      // how the last factorisation of this process was issued (0..3): diagnostics / bench
   std::atomic<int> win_pad{1};         // VUS_WIN_PAD=0: no padding blocks beside the critical workgroups (A/B timing)
+  std::atomic<int> win_fault{0};       // VUS_TUNE_WIN_FAULT (tests): one window workgroup exits at once, as if it had never become resident
+  static void env_knob(const char* name, long lo, long hi, std::atomic<int>& knob) {
+    const char* e = getenv(name);
+    if (!e) return;
+    char* end = nullptr;
+    errno = 0;
+    const long v = strtol(e, &end, 10);
+    if (end == e || *end != '\0' || errno != 0 || v < lo || v > hi) {
+      fprintf(stderr, "libvus_hip: ignoring %s=\"%s\" (an integer in [%ld, %ld] is expected)\n", name, e, lo, hi);
+      return;
+    }
+    knob = (int)v;
+  }
   Knobs() {
-    if (const char* e = getenv("VUS_BAND_MODE")) band_mode = atoi(e);
-    if (const char* e = getenv("VUS_CB_MAX_WG")) cb_max_wg = atoi(e);
-    if (const char* e = getenv("VUS_WIN_PAD")) win_pad = atoi(e);
+    // same bounds as vus_ba_set_tuning; anything else is reported and leaves the default (a typo such as
+    // VUS_BAND_MODE=auto used to read as 0 = the slowest mode, silently)
+    env_knob("VUS_BAND_MODE", -1, 3, band_mode);
+    env_knob("VUS_CB_MAX_WG", 0, 1 << 20, cb_max_wg);
+    env_knob("VUS_WIN_PAD", 0, 1, win_pad);
   }
 };
 Knobs g_knobs;
@@ -1548,8 +1565,8 @@ __device__ __forceinline__ void cb_drain() {   // every vector-memory operation 
 }
 
 // true once *f >= need; false after an abort (raised here when the wait expires)
-__device__ __forceinline__ bool cb_wait(const int* f, int need, int* abort_flag) {
-  for (int it = 0; it < CB_SPIN_LIMIT; ++it) {
+__device__ __forceinline__ bool cb_wait(const int* f, int need, int* abort_flag, int limit = CB_SPIN_LIMIT) {
+  for (int it = 0; it < limit; ++it) {
     if (cb_load(f) >= need) return true;
     if (__hip_atomic_load(abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return false;
     __builtin_amdgcn_s_sleep(1);
@@ -1996,6 +2013,8 @@ struct WinSys {
 struct WinSet {
   WinSys s[2];
   int count;
+  int spin;         // bound of every wait, in polls: sized from the chain length by window_launch
+  int fault;        // tests: the first bulk workgroup returns at once (a workgroup that never became resident)
 };
 constexpr int WIN_PUB = 6 * 256;
 constexpr int WIN_LDS_DOUBLES = 3 * UT * ULD + 3 * 16 * MLD + NB + 4 * BS_RHS_MAX * NB;
@@ -2104,7 +2123,7 @@ __device__ __forceinline__ void win_mfma_update(double4_t (&acc)[UQ], const doub
 }
 
 // ---- the critical workgroup of one system ----
-__device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, double* smem, int& s_bad, int& s_go) {
+__device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, int spin, double* smem, int& s_bad, int& s_go) {
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
   const int arow = lane & 15, kq = lane >> 4;
   const int n = B.n, NT = (n + PB - 1) / PB;
@@ -2161,7 +2180,7 @@ __device__ void win_critical(const WinSys& B, int band, int NE, int n_rhs, doubl
     bool okr[2];
     if (more) {
       if (I >= 2) {
-        if (tid == 0) s_go = hand_seen >= 2 || cb_wait(hand + I, 2, abort_flag);
+        if (tid == 0) s_go = hand_seen >= 2 || cb_wait(hand + I, 2, abort_flag, spin);
         lds_barrier();
         if (!s_go) { ok = false; break; }
       }
@@ -2383,7 +2402,7 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
       }
       if (J == p) {
         // ---- elimination of the tile: X = A L_D^-T with the inverse blocks the critical workgroup published ----
-        if (tid == 0) s_go = cb_wait(F, p + 1, abort_flag);
+        if (tid == 0) s_go = cb_wait(F, p + 1, abort_flag, S.spin);
         __syncthreads();
         if (!s_go) { live = false; continue; }
 #pragma unroll
@@ -2417,7 +2436,7 @@ __device__ void win_bulk(const WinSet& S, int slot, int band, int NE, int n_rhs,
         continue;
       }
       // ---- update with the solved rows of block rows I and J of panel p ----
-      if (tid == 0) s_go = cb_wait(xflag + I, p + 1, abort_flag) && (d == 0 || cb_wait(xflag + J, p + 1, abort_flag));
+      if (tid == 0) s_go = cb_wait(xflag + I, p + 1, abort_flag, S.spin) && (d == 0 || cb_wait(xflag + J, p + 1, abort_flag, S.spin));
       __syncthreads();
       if (!s_go) { live = false; continue; }
       {
@@ -2479,11 +2498,12 @@ __global__ __launch_bounds__(256, 2) void chol_window_kernel(WinSet S, int band,
   __shared__ int s_bad, s_go;
   const int bid = blockIdx.x;
   if (bid >= pad0 && bid < pad0 + S.count) return;
-  if (bid < S.count) win_critical(S.s[bid], band, NE, n_rhs, win_smem, s_bad, s_go);
+  if (S.fault && bid == S.count) return;
+  if (bid < S.count) win_critical(S.s[bid], band, NE, n_rhs, S.spin, win_smem, s_bad, s_go);
   else win_bulk(S, bid - S.count - (bid >= pad0 ? S.count : 0), band, NE, n_rhs, win_smem, s_go);
   if (threadIdx.x == 0)
-    for (int q = 0; q < S.count; ++q)
-      if (__hip_atomic_load(S.s[q].F + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) S.s[q].status[0] = -1;
+    for (int q = 0; q < S.count; ++q)       // an expired wait of THIS kernel: VUS_STATUS_WINDOW_EXPIRED, the caller may redo the solve launch by launch
+      if (__hip_atomic_load(S.s[q].F + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) S.s[q].status[0] = -3;
 }
 
 __global__ void add_diag_kernel(double* __restrict__ Sband, int n_poses, int band, double value) {
@@ -2793,6 +2813,11 @@ int window_launch(const BandSet& S, int band, int n_elim, int n_rhs, hipStream_t
   const int D = (band + PB - 1) / PB, M = D + 1;
   WinSet W;
   W.count = S.count;
+  // a poll is >= ~1 us (an sc1 load through the L2 and an s_sleep); a healthy chain advances one panel step in 12-30 us,
+  // and the longest legitimate wait is a late tile's for the whole chain: 512 polls per step is >= 10x that.  A
+  // workgroup that is not resident (something else holds its CU) therefore fails in tens of milliseconds, not seconds.
+  W.spin = 16384 + 512 * NE;
+  W.fault = g_knobs.win_fault.load(std::memory_order_relaxed);
   for (int q = 0; q < 2; ++q) {
     const BandSys& b = S.s[q < S.count ? q : 0];
     W.s[q] = WinSys{b.Sb, b.y, b.status, b.win_pub, b.win_F, b.n};
@@ -3167,7 +3192,7 @@ __global__ void split_gather_kernel(SplitPlan p, const double* __restrict__ yT, 
     // as a global scalar column + 1 (the column inside its own system for T, mapped back for R and the middle)
     const int a = status[0], b = st_R[0], c = st_M[0];
     int out = a;
-    if (a < 0 || b < 0 || c < 0) out = -1;
+    if (a < 0 || b < 0 || c < 0) out = min(a < 0 ? a : 0, min(b < 0 ? b : 0, c < 0 ? c : 0));    // -3 (window) before -1
     else if (a == 0 && b > 0) out = 6 * (p.n - 1 - (b - 1) / 6) + (b - 1) % 6 + 1;
     else if (a == 0 && c > 0) out = 6 * p.m + c;
     status[0] = out;
@@ -3250,6 +3275,10 @@ extern "C" int vus_ba_set_tuning(int knob, int value) {
       VUS_REQUIRE(value >= 0, "workgroup cap %d is negative", value);
       g_knobs.cb_max_wg = value;
       return VUS_OK;
+    case VUS_TUNE_WIN_FAULT:
+      VUS_REQUIRE(value == 0 || value == 1, "fault injection knob takes 0 or 1, not %d", value);
+      g_knobs.win_fault = value;
+      return VUS_OK;
     default:
       return vus::fail(VUS_E_INVALID, "unknown tuning knob %d", knob);
   }
@@ -3259,6 +3288,7 @@ extern "C" int vus_ba_get_tuning(int knob) {
   if (knob == VUS_TUNE_BAND_MODE) return g_knobs.band_mode.load();
   if (knob == VUS_TUNE_CB_MAX_WG) return g_knobs.cb_max_wg.load();
   if (knob == VUS_TUNE_LAST_BAND_MODE) return g_knobs.last_mode.load();
+  if (knob == VUS_TUNE_WIN_FAULT) return g_knobs.win_fault.load();
   return vus::fail(VUS_E_INVALID, "unknown tuning knob %d", knob);
 }
 

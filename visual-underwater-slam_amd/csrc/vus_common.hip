@@ -21,3 +21,7 @@ int fail(int code, const char* fmt, ...) {
 
 extern "C" int vus_abi_version(void) { return VUS_ABI_VERSION; }
 extern "C" const char* vus_last_error(void) { return vus::last_error_buf(); }
+#ifndef VUS_OFFLOAD_TARGET
+#define VUS_OFFLOAD_TARGET "unknown"
+#endif
+extern "C" const char* vus_build_target(void) { return VUS_OFFLOAD_TARGET; }

@@ -612,10 +612,19 @@ class _Column:
         self._view = None
 
     def arrays(self):
-        """(keys int64 [n], data f64 [n, width]) views of the live storage -- valid until the next append."""
+        """(keys int64 [n], data f64 [n, width]) VIEWS of the live storage.  While such a view is alive the stores cannot
+        grow (array.append raises BufferError), so no view ever leaves this class: callers get copies (take) and
+        write through put."""
         k = np.frombuffer(self.keys, dtype=np.int64) if len(self.keys) else np.zeros(0, np.int64)
         d = (np.frombuffer(self.data, dtype=np.float64) if len(self.data) else np.zeros(0)).reshape(-1, self.width)
         return k, d
+
+    def take(self, rows):
+        """Copy of the given rows [m, width]."""
+        return self.arrays()[1][rows]
+
+    def put(self, rows, values):
+        self.arrays()[1][rows] = values
 
     def view(self):
         """(sorted live keys, their rows)."""
@@ -689,26 +698,27 @@ class Values:
     insert_points = insert_point3_block
 
     def _stores(self, kind):
-        """Every array-backed store that can hold variables of `kind`: (find(keys) -> (rows, hit), data, kind)."""
+        """Every array-backed store that can hold variables of `kind`: (find(keys) -> (rows, hit), take(rows) -> copy,
+        put(rows, values), kind).  No view of a growing column is handed out (see _Column.arrays)."""
         for b in self._blk:
-            yield b.find, b.data, b.kind
+            yield b.find, b.data.__getitem__, b.data.__setitem__, b.kind
         for c in self._col.values():
             if len(c):
-                yield c.find, c.arrays()[1], c.kind
+                yield c.find, c.take, c.put, c.kind
 
     def _rows(self, kind, keys, what):
         """[n,w] array of the variables `keys` (int64 array) of the given kind; raises like gtsam's at*()."""
         keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(-1)
         out = np.empty((len(keys), _WIDTH[kind]))
         todo = np.ones(len(keys), bool)
-        for find, data, k in self._stores(kind):
+        for find, take, _, k in self._stores(kind):
             pos, hit = find(keys)
             hit &= todo
             if hit.any():
                 if k != kind:
                     bad = int(keys[np.nonzero(hit)[0][0]])
                     raise RuntimeError(f"Values: key \"{symbol_shorthand.key_string(bad)}\" does not hold what {what} asks for")
-                out[hit] = data[pos[hit]]
+                out[hit] = take(pos[hit])
                 todo &= ~hit
         for i in np.nonzero(todo)[0].tolist():      # what is left is absent, or an object of another type
             k = int(keys[i])
@@ -730,7 +740,7 @@ class Values:
     def _pose3_table(self):
         """(sorted keys, [n,12]) of every Pose3 variable."""
         sk, rows = self._col["pose3"].view()
-        ks, data = [sk], [self._col["pose3"].arrays()[1][rows]]
+        ks, data = [sk], [self._col["pose3"].take(rows)]
         for b in self._blk:
             if b.kind == "pose3":
                 ks.append(b.keys); data.append(b.data)
@@ -742,12 +752,12 @@ class Values:
         """Overwrite existing variables of `kind` (result write-back of the optimizer), vectorised."""
         keys = np.ascontiguousarray(keys, dtype=np.int64).reshape(-1)
         todo = np.ones(len(keys), bool)
-        for find, data, k in self._stores(kind):
+        for find, _, put, k in self._stores(kind):
             if k != kind:
                 continue
             pos, hit = find(keys)
             hit &= todo
-            data[pos[hit]] = rows[hit]
+            put(pos[hit], rows[hit])
             todo &= ~hit
         if todo.any():
             k = int(keys[np.nonzero(todo)[0][0]])

@@ -92,6 +92,51 @@ class _AuxPriors:
         self.x = self._cand
 
 
+_DVL_PROBES = None
+
+
+def lower_reference_dvl_factor(f):
+    """The reference builds its DVL factor as `gtsam.CustomFactor(Isotropic(3), [V(i), X(i)], partial(self.velocity_error,
+    measurement))` with a 1x3 measurement (batch.py:241-250).  A Python callback per factor cannot run on the GPU, and
+    the Jacobians that callback returns are ill-formed (3x3 for a 6-dof Pose3 key) -- but its RESIDUAL is
+    well defined: e = R_i m - v_i (batch.py:213-228).  This function recognises exactly that factor, by shape AND by
+    behaviour (the callback is evaluated at two probe states and must return R m - v to round-off), and returns the
+    equivalent DvlVelocityFactor (same residual, analytic Jacobians de/dv = -I, de/dX = [-R [m]x, 0]); anything else
+    returns None and stays refused."""
+    import functools
+    from . import CustomFactor, DvlVelocityFactor, Pose3, Rot3, Values
+    global _DVL_PROBES
+    if not isinstance(f, CustomFactor) or len(f._keys) != 2:
+        return None
+    kv, kx = f._keys
+    if _sym.symbolChr(kv) != "v" or _sym.symbolChr(kx) != "x":
+        return None
+    model, fn = f._model, f._fn
+    if model.dim() != 3 or not model.is_isotropic():
+        return None
+    if not isinstance(fn, functools.partial) or len(fn.args) != 1 or fn.keywords:
+        return None
+    m = np.asarray(fn.args[0], dtype=float)
+    if m.shape not in ((1, 3), (3,)) or not np.isfinite(m).all():
+        return None
+    m3 = m.reshape(3)
+    if _DVL_PROBES is None:
+        _DVL_PROBES = [(Rot3.Expmap(np.array(w)), np.array(v)) for w, v in
+                       (((0.3, -0.5, 0.8), (0.11, -0.23, 0.37)), ((-1.1, 0.4, 0.2), (-0.7, 0.05, 1.3)))]
+    try:
+        for R, v in _DVL_PROBES:
+            probe = Values()
+            probe.insert(kv, v)
+            probe.insert(kx, Pose3(R, np.array([0.4, -0.9, 2.0])))
+            e = np.asarray(fn(f, probe, None), dtype=float).reshape(-1)
+            want = R.matrix() @ m3 - v
+            if e.shape != (3,) or not np.allclose(e, want, rtol=0, atol=1e-12 * (1.0 + np.abs(want).max())):
+                return None
+    except Exception:                     # a callback that is not the reference's: refused by the caller
+        return None
+    return DvlVelocityFactor(model, kv, kx, m3)
+
+
 def _pack_graph(graph, values, device=None):
     """Factor graph + Values -> arrays for StereoBAProblem.  Raises on anything outside the built scope.
     The per-observation key -> index mapping (a sort of every landmark key) runs on `device` with torch when one
@@ -132,6 +177,15 @@ def _pack_graph(graph, values, device=None):
         elif isinstance(f, DvlVelocityFactor):
             dvl_f.append(f)
         elif isinstance(f, CustomFactor):
+            low = lower_reference_dvl_factor(f)
+            if low is not None:
+                if not dvl_f:
+                    import warnings
+                    warnings.warn("gtsam.CustomFactor(V(i), X(i), partial(velocity_error, m)) of batch.py:241-250 is solved as "
+                                  "DvlVelocityFactor: same residual R_i m - v_i, analytic Jacobians instead of the "
+                                  "callback's ill-formed ones (SURVEY.md D7)", stacklevel=3)
+                dvl_f.append(low)
+                continue
             raise NotImplementedError(
                 "gtsam.CustomFactor (a Python callback per factor) cannot run on the GPU; the reference's DVL factor "
                 "(batch.py:241-250) additionally returns ill-formed Jacobians (SURVEY.md D7): use "

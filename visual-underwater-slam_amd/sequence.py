@@ -35,6 +35,14 @@ def vector3(x, y, z):
     return np.array([x, y, z], dtype=float)
 
 
+def depth_from_pressure(press_abs):
+    """process_depth (batch.py:122-126): absolute pressure in hPa -> the depth that replaces the odometry's z
+    (process_odom, batch.py:133-134).  Pinned by tests/golden/ref_batch_*.npz (the reference's own output)."""
+    measured_pressure = press_abs * 100
+    pressure_diff = measured_pressure - 98250.0
+    return pressure_diff / (997 * 9.81)
+
+
 class BatchSequence:
     """AUV_ISAM's batch accumulators and graph construction (batch.py:74-118, 144-176, 253-305)."""
 

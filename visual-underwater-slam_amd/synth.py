@@ -96,6 +96,14 @@ STEREO_SIGMA = 10.0
 PRIOR_SIGMAS = (0.1, 0.1, 0.1, 0.3, 0.3, 0.3)
 
 
+# BASELINE.json configs[2] ("2000 keyframes x 50k landmarks", SURVEY.md 8: 1000 observations per keyframe = 2 M factors) as
+# arguments of ba_sequence(): landmarks nobody observes cannot enter a graph built like batch.py:295-305 and keyframes at
+# the edge of the sweep see fewer than the cap, so 50 000 drawn / cap 1000 gave 48 299 landmarks and 1 926 616 factors
+# (rounds 1-3).  52 000 drawn with a cap of 1032 gives 50 238 OBSERVED landmarks and 2 000 201 factors, band 224: the
+# smallest such pair on this trajectory (tests/test_ba_c3_gpu.py asserts both counts).
+CONFIGS2_BA = (2000, 52000, 1032)
+
+
 def _hash_uniform(idx, key):
     """uniform (0,1) doubles from a counter array and a scalar key (numpy)."""
     h = _mix32(np.asarray(idx, dtype=np.int64) ^ _mix32_scalar(key))
