@@ -296,6 +296,44 @@ int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lamb
                  const double* W, const double* V, const double* gl, const double* Hpp,
                  const double* gp, double* Vinv, double* Y, double* Sband, double* gs, void* stream);
 
+/* ---- the landmark elimination on the matrix cores (round 4): block-sparse S -= Y W^T by 8 x 8-pose TILE PAIRS ----
+ * The sum over landmarks IS the K dimension of a GEMM: for the tile pair (I, K) and every landmark j seen from both
+ * tiles, A_j = [Y_ij] (48 x 3, zero rows for poses of I that do not see j) and B_j = [W_kj] (48 x 3) are laid side by
+ * side along K and contracted with v_mfma_f64_16x16x4 into the 48 x 48 tile of S.  A W row is then fetched once per
+ * pose TILE that co-observes its landmark instead of once per co-observing pose (the per-pair kernel of rounds 1-3 fetched
+ * 8.3 GB of W rows per launch at configs[2]; this one 2.8 GB, in runs of up to 8 consecutive rows).
+ *
+ * vus_ba_tiles: unit u = (tile row I = u / (Dt + 1), tile distance d = u % (Dt + 1)), Dt = ceil(band / 8), covers the
+ * pose blocks (i, k) with i / 8 = I, k / 8 = I - d.  entries[unit_ptr[u] .. unit_ptr[u + 1]) are its landmarks in
+ * ascending order, four ints each: a = first L-order row of the landmark in tile I, b = the same for tile I - d,
+ * j = the landmark, mask = (8-bit mask of the poses of tile I that see it) | (the same for tile I - d) << 8 -- the rows of
+ * a tile are consecutive in L-order, row t belonging to the pose of the t-th set bit.  order[]: the units, largest first
+ * (a schedule, not a result).  Built once per graph, two launches + a sort (csrc/pack.hip):
+ *   vus_ba_tiles_count   lm_entries[j] = entries landmark j contributes = m (m + 1) / 2 for m pose tiles that see it
+ *   (host)               lm_base = exclusive prefix sums (vus_exclusive_scan_i32); the total sizes `entries`
+ *   vus_ba_tiles_fill    unit_ptr [n_tiles * (Dt + 1) + 1], entries [n_entries, 4], order [n_tiles * (Dt + 1)];
+ *                        work: vus_ba_tiles_work_bytes(n_entries) bytes
+ * The reference has no counterpart: GTSAM finds its elimination structure inside optimize() (batch.py:337). */
+typedef struct vus_ba_tiles {
+  int band;              /* in poses; >= the widest keyframe span of a landmark */
+  int n_tiles;           /* ceil(n_poses / 8) */
+  int n_units;           /* n_tiles * (ceil(band / 8) + 1) */
+  int n_entries;
+  const int* unit_ptr;   /* [n_units + 1] */
+  const int* entries;    /* [n_entries, 4] (16-byte aligned) */
+  const int* order;      /* [n_units] */
+} vus_ba_tiles;
+int vus_ba_tiles_count(const vus_ba_problem* P, int* lm_entries, void* stream);
+long long vus_ba_tiles_work_bytes(int n_entries);
+int vus_ba_tiles_fill(const vus_ba_problem* P, int band, const int* lm_base, int n_entries, int* unit_ptr, int* entries,
+                      int* order, void* work, long long work_bytes, void* stream);
+/* vus_ba_schur through the tile pairs: same outputs (Vinv, S band = Hpp + lambda I - sum_j Y W^T, gs = gp - sum Y gl); every
+ * stored block of the band is written, none is accumulated into.  band_nodes: the half-bandwidth of Sband's storage in
+ * NODES (>= pose_stride * T->band).  counter: one int of device scratch (the unit queue). */
+int vus_ba_schur_tiles(const vus_ba_problem* P, const vus_ba_tiles* T, double lambda, const double* W, const double* V,
+                       const double* gl, const double* Hpp, const double* gp, double* Vinv, double* Sband, int band_nodes,
+                       double* gs, int* counter, void* stream);
+
 /* Sband(i,i) += value * I for every pose.  Used by the landmark-sharded multi-GPU solve: after the
  * all-reduce of the per-rank bands the pose damping lambda*I has been added once per rank, and
  * value = -(n_ranks-1)*lambda restores a single copy. */

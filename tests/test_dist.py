@@ -212,7 +212,11 @@ def test_sharded_lm_two_ranks_at_the_configs4_size_matches_single(gpu):
     assert rep.status == 0
     for r in range(2):
         p, pt, hist, tries = out[r]
-        assert tries == rep.tries and np.allclose(hist, rep.err_hist, rtol=1e-9)
+        # Same trials; the error after the first two steps agrees to 1e-6 only: at lambda = 1e-5 the reduced system of a
+        # 10 000-pose chain with one prior has cond ~ 1e10, so the step carries cond * eps of whatever the summation
+        # order of the reduce contributes (measured 4e-8 and 7e-7) -- and LM then walks both runs to the SAME optimum:
+        assert tries == rep.tries and np.allclose(hist, rep.err_hist, rtol=1e-5)
+        assert np.isclose(hist[-1], rep.err_hist[-1], rtol=1e-11)
         assert np.abs(p - poses.cpu().numpy()).max() < 1e-9 * max(1.0, np.abs(p).max())
         assert np.abs(pt - points.cpu().numpy()).max() < 1e-8 * np.abs(pt).max()
     assert np.array_equal(out[0][0], out[1][0])

@@ -69,6 +69,13 @@ struct Knobs {
 };
 Knobs g_knobs;
 
+typedef double double4_t __attribute__((ext_vector_type(4)));
+typedef double d2a_t __attribute__((ext_vector_type(2), aligned(16)));
+
+// the wave's index in its workgroup as a SCALAR: branches on it are scalar branches (derived from threadIdx.x alone the
+// compiler treats it as divergent and wraps every wave-specialised region in exec-mask saves and restores)
+__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 // compute units of the current device (cached per device)
 int device_cu_count() {
   static std::mutex mu;
@@ -663,6 +670,147 @@ __global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure
   }   // rows of this workgroup
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// The landmark elimination on the matrix cores: S(I,K) = init - sum_j A_j B_j^T per 8 x 8-pose tile pair (include/vus.h,
+// vus_ba_tiles).  A workgroup of four waves owns one unit at a time (persistent, units handed out largest first through
+// a global counter).  A wave takes the chunks c = wave, wave + 4, ... of the unit's landmark list, ST_CH landmarks each:
+// it stages A = [W_ij Vinv_j] and B = [W_kj] of the chunk K-MAJOR into its own LDS panels (panel[k][row], row = 6 * pose
+// + component: an MFMA operand fetch is 16 consecutive doubles per k), zero rows where a pose does not see the landmark,
+// and runs the 3 x 3 output tiles of 16 x 16 over the chunk's K = 3 ST_CH columns.  No workgroup barrier inside a unit:
+// the panels are wave-private, LDS operations of one wave complete in order.  The four partial tiles meet in LDS at the
+// end (fixed order: the result does not depend on scheduling) and leave as 16-byte vectors in the band's address order.
+constexpr int ST_CH = 8;                       // landmarks per chunk
+constexpr int ST_KC = 3 * ST_CH;               // K columns per chunk: 6 steps of v_mfma_f64_16x16x4
+constexpr int ST_LD = 50;                      // panel stride in doubles (48 rows + 2)
+constexpr int ST_PANEL = ST_KC * ST_LD;
+constexpr int ST_WAVES = 4;
+constexpr int ST_WAVE_DOUBLES = 2 * ST_PANEL + 6 * ST_CH + 2 * ST_CH;     // panels, Vinv table, the chunk's entries (int4)
+static_assert(2 * ST_PANEL >= 48 * 48, "a wave's panels also hold its partial 48 x 48 tile");
+static_assert(ST_KC % 4 == 0, "whole MFMA K steps");
+
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+template <bool W_L_ORDER>
+__global__ __launch_bounds__(64 * ST_WAVES, 2) void schur_tiles_kernel(vus_ba_tiles T, int n_poses, int ps, int band_nodes,
+                                                                       double lambda, const double* __restrict__ W,
+                                                                       const int* __restrict__ obs_ppos,
+                                                                       const double* __restrict__ Vinv,
+                                                                       const double* __restrict__ Hpp,
+                                                                       double* __restrict__ Sband, int* __restrict__ counter) {
+  extern __shared__ __attribute__((aligned(16))) double st_smem[];
+  __shared__ int s_unit;
+  const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
+  double* __restrict__ PA = st_smem + wave * ST_WAVE_DOUBLES;
+  double* __restrict__ PB = PA + ST_PANEL;
+  double* __restrict__ vtab = PB + ST_PANEL;
+  int4* __restrict__ etab = reinterpret_cast<int4*>(vtab + 6 * ST_CH);
+  const int4* __restrict__ entries = reinterpret_cast<const int4*>(T.entries);
+  const int dt1 = T.n_units / T.n_tiles;
+  const int arow = lane & 15, kq = lane >> 4;
+  while (true) {
+    __syncthreads();                 // the previous unit's partial tiles have been consumed, s_unit has been read
+    if (tid == 0) s_unit = atomicAdd(counter, 1);
+    __syncthreads();
+    const int ui = s_unit;
+    if (ui >= T.n_units) break;
+    const int u = T.order[ui];
+    const int I = u / dt1, d = u - I * dt1, K = I - d;
+    if (K < 0) continue;             // left of the first pose: nothing is stored there
+    const int e0 = T.unit_ptr[u], e1 = T.unit_ptr[u + 1];
+    const int n_chunks = (e1 - e0 + ST_CH - 1) / ST_CH;
+    double4_t acc[3][3];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc[t][q] = double4_t{0.0, 0.0, 0.0, 0.0};
+    for (int c = wave; c < n_chunks; c += ST_WAVES) {
+      // the chunk's entries and the Vinv of their landmarks -> the wave's tables
+      if (lane < ST_CH) {
+        const int e = e0 + ST_CH * c + lane;
+        etab[lane] = e < e1 ? entries[e] : make_int4(0, 0, -1, 0);
+      }
+      wave_lds_fence();
+      if (lane < 6 * ST_CH) {
+        const int l = lane / 6, j = etab[l].z;
+        vtab[lane] = j >= 0 ? Vinv[6 * (size_t)j + (lane - 6 * l)] : 0.0;
+      }
+      wave_lds_fence();
+      // task = (landmark l, pose q of the tile, row r of the 6 x 3 block): three consecutive doubles of a W row
+#pragma unroll
+      for (int side = 0; side < 2; ++side) {
+#pragma unroll
+        for (int rnd = 0; rnd < 6 * ST_CH / 8; ++rnd) {            // 48 ST_CH tasks, 64 lanes
+          const int id = 64 * rnd + lane;
+          const int l = id / 48, qr = id - 48 * l, q = qr / 6, r = qr - 6 * q;
+          const int4 en = etab[l];
+          const int m = side == 0 ? (en.w & 0xFF) : ((en.w >> 8) & 0xFF);
+          const bool present = (m >> q) & 1;
+          const int row = (side == 0 ? en.x : en.y) + __popc(m & ((1 << q) - 1));
+          double w0 = 0.0, w1 = 0.0, w2 = 0.0;
+          if (present) {
+            const size_t slot = W_L_ORDER ? (size_t)row : (size_t)obs_ppos[row];
+            const double* src = W + 18 * slot + 3 * r;
+            w0 = src[0]; w1 = src[1]; w2 = src[2];
+          }
+          double* dst = (side == 0 ? PA : PB) + (3 * l) * ST_LD + qr;
+          if (side == 0) {           // Y = W Vinv (symmetric 3 x 3: xx xy xz yy yz zz)
+            const double* v = vtab + 6 * l;
+            dst[0] = w0 * v[0] + w1 * v[1] + w2 * v[2];
+            dst[ST_LD] = w0 * v[1] + w1 * v[3] + w2 * v[4];
+            dst[2 * ST_LD] = w0 * v[2] + w1 * v[4] + w2 * v[5];
+          } else {
+            dst[0] = w0; dst[ST_LD] = w1; dst[2 * ST_LD] = w2;
+          }
+        }
+      }
+      wave_lds_fence();
+#pragma unroll
+      for (int s2 = 0; s2 < ST_KC / 4; ++s2) {
+        double a[3], b[3];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          a[t] = PA[(4 * s2 + kq) * ST_LD + 16 * t + arow];
+          b[t] = PB[(4 * s2 + kq) * ST_LD + 16 * t + arow];
+        }
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[q], acc[t][q], 0, 0, 0);
+      }
+      wave_lds_fence();              // the operands have been read before the next chunk overwrites the panels
+    }
+    // the wave's partial tile, row-major [48][48], over its own panels.  C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) PA[(16 * t + kq + 4 * r) * 48 + 16 * q + arow] = acc[t][q][r];
+    __syncthreads();
+    // out: pose row i of the tile = the blocks (i, 8K + 7 .. 8K), 2304 contiguous bytes; vector v = 144 ii + 18 o + e / 2
+    for (int v = tid; v < 8 * 144; v += 64 * ST_WAVES) {
+      const int ii = v / 144, w = v - 144 * ii, o = w / 18, e = 2 * (w - 18 * o), kk = 7 - o;
+      const int i = 8 * I + ii, k = 8 * K + kk;
+      if (i >= n_poses || k > i || ps * (i - k) > band_nodes) continue;
+      const int rr = e / 6, cc = e - 6 * rr;
+      const int at = (6 * ii + rr) * 48 + 6 * kk + cc;
+      double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < ST_WAVES; ++wv) {
+        s0 += st_smem[wv * ST_WAVE_DOUBLES + at];
+        s1 += st_smem[wv * ST_WAVE_DOUBLES + at + 1];
+      }
+      d2a_t out = d2a_t{-s0, -s1};
+      if (i == k) {
+        out.x += Hpp[36 * (size_t)i + e] + (rr == cc ? lambda : 0.0);
+        out.y += Hpp[36 * (size_t)i + e + 1] + (rr == cc + 1 ? lambda : 0.0);
+      }
+      *reinterpret_cast<d2a_t*>(Sband + 36 * ((size_t)(ps * i) * (band_nodes + 1) + (size_t)ps * (i - k)) + e) = out;
+    }
+  }
+}
+
 // gs_i = gp_i - sum_{slots of pose i} W_s (Vinv gl)[point(s)]   (one wave per pose)
 __global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const double* __restrict__ W,
                                                        const double* __restrict__ Vinv,
@@ -707,9 +855,6 @@ __device__ __forceinline__ const double* blk_ptr(const double* Sb, int band, int
   return Sb + 36 * ((size_t)i * (band + 1) + (i - k));
 }
 
-// the wave's index in its workgroup as a SCALAR: branches on it are scalar branches (derived from threadIdx.x alone the
-// compiler treats it as divergent and wraps every wave-specialised region in exec-mask saves and restores)
-__device__ __forceinline__ int wave_index() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
 
 template <int CTRL>
 __device__ __forceinline__ double dpp_f64(double v) {      // v of the lane the DPP control selects
@@ -972,8 +1117,6 @@ constexpr int UMT = UT / 16;      // MFMA tiles per side
 constexpr int UQ = (UMT * UMT + 3) / 4;   // MFMA tiles per wave
 constexpr int UTP = UT / 6;       // poses per tile
 constexpr int ULD = NB + 1;       // LDS row stride (doubles)
-typedef double double4_t __attribute__((ext_vector_type(4)));
-typedef double d2a_t __attribute__((ext_vector_type(2), aligned(16)));
 constexpr int MLD = 17;           // LDS row stride of the 16x16 inverse blocks
 
 #ifdef VUS_TIMING
@@ -2712,6 +2855,43 @@ extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, 
   }
   schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, W, Vinv, gl, gp, gs);
   VUS_CHECK_LAUNCH("ba_schur");
+  return VUS_OK;
+}
+
+
+extern "C" int vus_ba_schur_tiles(const vus_ba_problem* P, const vus_ba_tiles* T, double lambda, const double* W,
+                                  const double* V, const double* gl, const double* Hpp, const double* gp, double* Vinv,
+                                  double* Sband, int band_nodes, double* gs, int* counter, void* stream) {
+  VUS_REQUIRE(P != nullptr && T != nullptr, "null problem or tile structure");
+  const int nP = P->n_poses, nL = P->n_points, nO = P->n_obs;
+  VUS_REQUIRE(Hpp && gp && Sband && gs && counter, "null buffer");
+  VUS_REQUIRE(nL == 0 || (V && Vinv && gl), "null landmark buffer");
+  VUS_REQUIRE(nO == 0 || W, "null W");
+  const int ps = pose_stride(*P);
+  VUS_REQUIRE(T->n_tiles == (nP + 7) / 8 && T->n_units == T->n_tiles * ((T->band + 7) / 8 + 1), "tile structure of another problem");
+  VUS_REQUIRE(band_nodes >= ps * T->band, "band_nodes=%d is narrower than the tile structure's %d poses", band_nodes, T->band);
+  VUS_REQUIRE(T->n_units == 0 || (T->unit_ptr && T->order), "null tile lists");
+  hipStream_t st = vus::as_stream(stream);
+  // with velocity nodes between the poses (ps = 2) the blocks the tiles do not cover belong to the inertial factors:
+  // zeroed here.  With ps = 1 every stored block (i, k), 0 <= k <= i, i - k <= band, is written by its tile pair; the
+  // slots left of pose 0 (k < 0) are never read by the solvers (band_index.h masks them) but are kept finite.
+  VUS_CHECK_HIP(hipMemsetAsync(Sband, 0, sizeof(double) * 36 * (size_t)nP * ps * (band_nodes + 1), st));
+  if (ps > 1) VUS_CHECK_HIP(hipMemsetAsync(gs, 0, sizeof(double) * 6 * (size_t)nP * ps, st));
+  VUS_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(int), st));
+  if (nL > 0) vinv_kernel<<<cdiv(nL, 256), 256, 0, st>>>(nL, lambda, V, Vinv);
+  {
+    constexpr int lds = ST_WAVES * ST_WAVE_DOUBLES * (int)sizeof(double);
+    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(schur_tiles_kernel<false>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    int n_cu = device_cu_count();
+    if (n_cu < 8) n_cu = 256;
+    int wg = 2 * n_cu;
+    if (wg > T->n_units) wg = T->n_units;
+    if (wg > 0)
+      schur_tiles_kernel<false><<<wg, 64 * ST_WAVES, lds, st>>>(*T, nP, ps, band_nodes, lambda, W, P->obs_ppos, Vinv, Hpp, Sband, counter);
+  }
+  schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, W, Vinv, gl, gp, gs);
+  VUS_CHECK_LAUNCH("ba_schur_tiles");
   return VUS_OK;
 }
 

@@ -397,6 +397,89 @@ __global__ __launch_bounds__(RS_THREADS) void head_ranks_kernel(const unsigned l
   }
 }
 
+
+// ---- tile-pair structure of the landmark elimination (vus_ba_tiles, include/vus.h) ------------------------------------
+// A landmark's L-order run (poses ascending) falls into SEGMENTS of equal pose tile (pose >> 3); every pair of segments
+// (u >= v) is one entry of the unit (tile of u, tile distance): the landmark's rows of the two tiles, as first L-order row
+// + 8-bit pose mask each.  Entries are emitted landmark by landmark and sorted by unit with the stable radix sort above:
+// inside a unit they ascend by landmark, whatever the launch geometry -- the summation order of the Schur kernel is fixed.
+constexpr int TILE_POSES = 8;
+
+__global__ void tiles_count_kernel(const int* __restrict__ point_ptr, const int* __restrict__ obs_pose, int n_points,
+                                   int* __restrict__ cnt) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_points) return;
+  int m = 0, prev = -1;
+  for (int a = point_ptr[j]; a < point_ptr[j + 1]; ++a) {
+    const int t = obs_pose[a] / TILE_POSES;
+    m += t != prev;
+    prev = t;
+  }
+  cnt[j] = m * (m + 1) / 2;
+}
+
+__global__ void tiles_emit_kernel(const int* __restrict__ point_ptr, const int* __restrict__ obs_pose, int n_points, int dt1,
+                                  const int* __restrict__ base, unsigned* __restrict__ key, int4* __restrict__ ent) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_points) return;
+  const int a0 = point_ptr[j], a1 = point_ptr[j + 1];
+  int out = base[j];
+  for (int a = a0; a < a1;) {
+    const int tu = obs_pose[a] / TILE_POSES, au = a;
+    int mu = 0;
+    for (; a < a1 && obs_pose[a] / TILE_POSES == tu; ++a) mu |= 1 << (obs_pose[a] % TILE_POSES);
+    for (int b = a0; b < a;) {                      // the segments up to and including u, in order
+      const int tv = obs_pose[b] / TILE_POSES, bv = b;
+      int mv = 0;
+      for (; b < a1 && obs_pose[b] / TILE_POSES == tv; ++b) mv |= 1 << (obs_pose[b] % TILE_POSES);
+      key[out] = (unsigned)(tu * dt1 + (tu - tv));
+      ent[out] = make_int4(au, bv, j, mu | (mv << 8));
+      ++out;
+    }
+  }
+}
+
+__global__ void tiles_gather_kernel(const int4* __restrict__ ent, const int* __restrict__ perm, int n, int4* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = ent[perm[i]];
+}
+
+// unit_ptr[u] = first sorted entry with key >= u (u = 0 .. n_units)
+__global__ void tiles_ptr_kernel(const unsigned* __restrict__ sk, int n, int n_units, int* __restrict__ unit_ptr) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u > n_units) return;
+  int lo = 0, hi = n;
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sk[mid] < (unsigned)u) lo = mid + 1;
+    else hi = mid;
+  }
+  unit_ptr[u] = lo;
+}
+
+// order[] = the units by descending size class (bit length of the entry count): the persistent workgroups of the Schur
+// kernel take them largest first.  Only the schedule depends on it, no result.  One workgroup.
+__global__ __launch_bounds__(1024) void tiles_order_kernel(const int* __restrict__ unit_ptr, int n_units, int* __restrict__ order) {
+  __shared__ int s_cls[33];
+  const int tid = threadIdx.x;
+  if (tid < 33) s_cls[tid] = 0;
+  __syncthreads();
+  for (int u = tid; u < n_units; u += 1024) {
+    const int c = unit_ptr[u + 1] - unit_ptr[u];
+    atomicAdd(&s_cls[c > 0 ? 31 - __clz(c) + 1 : 0], 1);
+  }
+  __syncthreads();
+  if (tid == 0) {
+    int run = 0;
+    for (int c = 32; c >= 0; --c) { const int n = s_cls[c]; s_cls[c] = run; run += n; }
+  }
+  __syncthreads();
+  for (int u = tid; u < n_units; u += 1024) {
+    const int c = unit_ptr[u + 1] - unit_ptr[u];
+    order[atomicAdd(&s_cls[c > 0 ? 31 - __clz(c) + 1 : 0], 1)] = u;
+  }
+}
+
 int bits_for(unsigned long long max_value) {
   int b = 1;
   while (b < 64 && (max_value >> b) != 0) ++b;
@@ -541,5 +624,51 @@ extern "C" int vus_exclusive_scan_i32(const int* in, int n, int* out, long long*
   // n is a number of poses (thousands): one workgroup
   scan_i32_kernel<<<1, 1024, 0, vus::as_stream(stream)>>>(in, n, out, total);
   VUS_CHECK_LAUNCH("exclusive_scan_i32");
+  return VUS_OK;
+}
+
+extern "C" int vus_ba_tiles_count(const vus_ba_problem* P, int* lm_entries, void* stream) {
+  VUS_REQUIRE(P != nullptr && lm_entries != nullptr, "null argument");
+  VUS_REQUIRE(P->n_points >= 1 && P->point_ptr && P->obs_pose, "the problem holds no landmark");
+  tiles_count_kernel<<<cdiv(P->n_points, 256), 256, 0, vus::as_stream(stream)>>>(P->point_ptr, P->obs_pose, P->n_points, lm_entries);
+  VUS_CHECK_LAUNCH("ba_tiles_count");
+  return VUS_OK;
+}
+
+extern "C" long long vus_ba_tiles_work_bytes(int n_entries) {
+  const size_t n = (size_t)(n_entries > 0 ? n_entries : 1);
+  // keys in and out, the identity and the permutation, the unsorted entries, the sort's own scratch
+  return (long long)(2 * align256(4 * n) + 2 * align256(4 * n) + align256(16 * n) + sort_temp_bytes((int)n) + 1024);
+}
+
+extern "C" int vus_ba_tiles_fill(const vus_ba_problem* P, int band, const int* lm_base, int n_entries, int* unit_ptr,
+                                 int* entries, int* order, void* work, long long work_bytes, void* stream) {
+  VUS_REQUIRE(P != nullptr && lm_base && unit_ptr && order && work, "null argument");
+  VUS_REQUIRE(band >= 0 && n_entries >= 0 && (entries || n_entries == 0), "band=%d n_entries=%d", band, n_entries);
+  VUS_REQUIRE(work_bytes >= vus_ba_tiles_work_bytes(n_entries), "workspace of %lld bytes, %lld needed", work_bytes,
+              vus_ba_tiles_work_bytes(n_entries));
+  hipStream_t st = vus::as_stream(stream);
+  const int n_tiles = (P->n_poses + TILE_POSES - 1) / TILE_POSES, dt1 = (band + TILE_POSES - 1) / TILE_POSES + 1;
+  VUS_REQUIRE((long long)n_tiles * dt1 < (1ll << 31), "%d pose tiles x %d tile distances exceed the unit index", n_tiles, dt1);
+  const int n_units = n_tiles * dt1, n = n_entries;
+  if (n > 0) {
+    Carve c{static_cast<char*>(work), (size_t)work_bytes};
+    unsigned* key = c.take<unsigned>(n);
+    unsigned* sk = c.take<unsigned>(n);
+    int* iota = c.take<int>(n);
+    int* perm = c.take<int>(n);
+    int4* ent = c.take<int4>(n);
+    SortTemp tmp;
+    VUS_REQUIRE(key && sk && iota && perm && ent && take_sort_temp(c, n, tmp), "workspace too small");
+    iota_kernel<<<cdiv(n, 256), 256, 0, st>>>(iota, n);
+    tiles_emit_kernel<<<cdiv(P->n_points, 256), 256, 0, st>>>(P->point_ptr, P->obs_pose, P->n_points, dt1, lm_base, key, ent);
+    if (int rc = radix_sort_pairs<unsigned>(key, sk, iota, perm, n, bits_for((unsigned long long)n_units), tmp, st)) return rc;
+    tiles_gather_kernel<<<cdiv(n, 256), 256, 0, st>>>(ent, perm, n, reinterpret_cast<int4*>(entries));
+    tiles_ptr_kernel<<<cdiv(n_units + 1, 256), 256, 0, st>>>(sk, n, n_units, unit_ptr);
+  } else {
+    VUS_CHECK_HIP(hipMemsetAsync(unit_ptr, 0, sizeof(int) * (size_t)(n_units + 1), st));
+  }
+  tiles_order_kernel<<<1, 1024, 0, st>>>(unit_ptr, n_units, order);
+  VUS_CHECK_LAUNCH("ba_tiles_fill");
   return VUS_OK;
 }
