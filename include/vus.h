@@ -197,7 +197,8 @@ int vus_triangulate(const double* feat, int n, const double* cam, const double* 
  * Observations are stored twice-indexed:
  *   "L-order": sorted by (point, pose); point_ptr is the CSR row pointer over it;
  *   "P-order": sorted by (pose, point); pose_ptr is the CSR row pointer over it.
- * Per-observation Jacobian products W, Y live in P-order.
+ * Per-observation Jacobian products W, Y live in L-order (round 4; rounds 1-3 kept them in P-order): a landmark's rows
+ * are consecutive, poses ascending -- its rows of an 8-pose tile are one run.
  * Empty inputs: n_points == 0 and n_obs == 0 are valid (a graph of pose priors only); the arrays and the
  * buffers of an empty dimension may then be NULL.  pose_ptr is always required (n_poses + 1 entries).
  * ---------------------------------------------------------------------------------------- */
@@ -246,37 +247,8 @@ typedef struct vus_nav_factors {
   const double* vprior_w;    /* [n_vprior,3] 1/sigma */
 } vus_nav_factors;
 
-/* Block structure of the reduced camera system S (built once per graph by the host):
- * lower block band of half-width `band` pose blocks; non-zero block (blk_i >= blk_k) number q owns
- * pairs [blk_ptr[q], blk_ptr[q+1]) of P-order slots (pair_a: the observation of pose blk_i,
- * pair_b: of pose blk_k) that see the same point.  S band storage: [n_poses, band+1, 6, 6],
- * entry (i, s) = block (i, i - s). */
-typedef struct vus_ba_structure {
-  int band;
-  int n_blocks;
-  int n_pairs;
-  const int* blk_ptr;      /* [n_blocks+1] */
-  const int* blk_i;        /* [n_blocks] */
-  const int* blk_k;        /* [n_blocks] */
-  const int* pair_a;       /* [n_pairs] */
-  const int* pair_b;       /* [n_pairs] */
-} vus_ba_structure;
-
-/* vus_ba_structure built on the device, one workgroup per pose row (csrc/structure.hip); bit-identical to the
- * host-side construction (visual-underwater-slam_amd/ba_pack.py build_structure): blocks ordered by (i, k), the pairs
- * of a block by ascending slot of pose i.  The reference has no counterpart: GTSAM finds this structure inside
- * LevenbergMarquardtOptimizer.optimize() (batch.py:337) by symbolic elimination.
- *   band        max over landmarks of (last - first observing pose), in poses; band + 1 <= 6143
- *   step 1      row_blocks[i] / row_pairs[i] = non-zero blocks / pairs of block row i        [n_poses] each
- *   (host)      blk_base / pair_base = exclusive prefix sums of those, [n_poses + 1]; the totals size the lists
- *   step 2      fills blk_ptr [n_blocks+1], blk_i, blk_k [n_blocks], pair_a, pair_b [n_pairs]
- * Needs n_obs >= 1.  Only the index arrays of P are read. */
-int vus_ba_structure_count(const vus_ba_problem* P, int band, int* row_blocks, int* row_pairs, void* stream);
-int vus_ba_structure_fill(const vus_ba_problem* P, int band, const int* blk_base, const int* pair_base,
-                          int* blk_ptr, int* blk_i, int* blk_k, int* pair_a, int* pair_b, void* stream);
-
 /* Linearise every factor at (poses, points):
- *   W   [n_obs,18]  H1^T H2 (6x3 row-major) per observation, P-order, whitened
+ *   W   [n_obs,18]  H1^T H2 (6x3 row-major) per observation, L-order, whitened
  *   V   [n_points,6] sum H2^T H2, upper triangle (xx,xy,xz,yy,yz,zz)
  *   gl  [n_points,3] sum H2^T r
  *   Hpp [n_poses,36] sum H1^T H1 + prior information;  gp [n_poses,6] sum H1^T r + prior part
@@ -288,15 +260,7 @@ int vus_ba_linearize(const vus_ba_problem* P, const double* poses, const double*
                      double* W, double* V, double* gl, double* Hpp, double* gp, double* err,
                      double* work, void* stream);
 
-/* Damped landmark elimination for one lambda (lambda*I damping, gtsam diagonalDamping=false):
- *   Vinv [n_points,6] = (V + lambda I)^-1 (upper triangle);  Y [n_obs,18] = W Vinv (P-order), OPTIONAL output
- *   (NULL: not written; the kernels form the rows they need on the fly);
- *   S band (see vus_ba_structure) = Hpp + lambda I - sum_j Y W^T;  gs [n_poses,6] = gp - sum Y gl. */
-int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lambda,
-                 const double* W, const double* V, const double* gl, const double* Hpp,
-                 const double* gp, double* Vinv, double* Y, double* Sband, double* gs, void* stream);
-
-/* ---- the landmark elimination on the matrix cores (round 4): block-sparse S -= Y W^T by 8 x 8-pose TILE PAIRS ----
+/* ---- the landmark elimination on the matrix cores: block-sparse S -= Y W^T by 8 x 8-pose TILE PAIRS (round 4) ----
  * The sum over landmarks IS the K dimension of a GEMM: for the tile pair (I, K) and every landmark j seen from both
  * tiles, A_j = [Y_ij] (48 x 3, zero rows for poses of I that do not see j) and B_j = [W_kj] (48 x 3) are laid side by
  * side along K and contracted with v_mfma_f64_16x16x4 into the 48 x 48 tile of S.  A W row is then fetched once per
@@ -327,12 +291,16 @@ int vus_ba_tiles_count(const vus_ba_problem* P, int* lm_entries, void* stream);
 long long vus_ba_tiles_work_bytes(int n_entries);
 int vus_ba_tiles_fill(const vus_ba_problem* P, int band, const int* lm_base, int n_entries, int* unit_ptr, int* entries,
                       int* order, void* work, long long work_bytes, void* stream);
-/* vus_ba_schur through the tile pairs: same outputs (Vinv, S band = Hpp + lambda I - sum_j Y W^T, gs = gp - sum Y gl); every
- * stored block of the band is written, none is accumulated into.  band_nodes: the half-bandwidth of Sband's storage in
- * NODES (>= pose_stride * T->band).  counter: one int of device scratch (the unit queue). */
-int vus_ba_schur_tiles(const vus_ba_problem* P, const vus_ba_tiles* T, double lambda, const double* W, const double* V,
-                       const double* gl, const double* Hpp, const double* gp, double* Vinv, double* Sband, int band_nodes,
-                       double* gs, int* counter, void* stream);
+/* Damped landmark elimination for one lambda (lambda*I damping, gtsam diagonalDamping=false):
+ *   Vinv [n_points,6] = (V + lambda I)^-1 (upper triangle);  Y [n_obs,18] = W Vinv (L-order), OPTIONAL output
+ *   (NULL: not written; the kernel forms the rows it needs on the fly);
+ *   S band [n_nodes, band_nodes + 1, 36], entry (i, s) = the 6 x 6 block (i, i - s), = Hpp + lambda I - sum_j Y W^T: every
+ *   stored block is written (none accumulated into), diagonal blocks whole;  gs [n_nodes,6] = gp - sum Y gl.
+ * band_nodes: the half-bandwidth of Sband's storage in NODES (>= pose_stride * T->band).  counter: one int of device
+ * scratch (the unit queue).  Replaces what GTSAM's elimination does inside optimize(), batch.py:337. */
+int vus_ba_schur(const vus_ba_problem* P, const vus_ba_tiles* T, double lambda, const double* W, const double* V,
+                 const double* gl, const double* Hpp, const double* gp, double* Vinv, double* Y, double* Sband,
+                 int band_nodes, double* gs, int* counter, void* stream);
 
 /* Sband(i,i) += value * I for every pose.  Used by the landmark-sharded multi-GPU solve: after the
  * all-reduce of the per-rank bands the pose damping lambda*I has been added once per rank, and

@@ -337,13 +337,28 @@ def ba_structure(P, band):
     return out
 
 
+def ba_tiles(P, band):
+    """vus_ba_tiles arrays by the plain statement (oracle/vus_oracle_pack.c): dict with unit_ptr, entries [n,4], order."""
+    cnt = np.zeros(max(P.n_points, 1), np.int32)
+    _check(lib().vus_ba_tiles_count_cpu(P.ref(), _p(cnt)), "ba_tiles_count")
+    base = np.zeros(P.n_points + 1, np.int32); base[1:] = np.cumsum(cnt[:P.n_points])
+    n = int(base[-1])
+    n_tiles, dt1 = (P.n_poses + 7) // 8, (int(band) + 7) // 8 + 1
+    out = {"band": int(band), "n_tiles": n_tiles, "n_units": n_tiles * dt1, "n_entries": n, "lm_entries": cnt[:P.n_points],
+           "unit_ptr": np.zeros(n_tiles * dt1 + 1, np.int32), "entries": np.zeros((max(n, 1), 4), np.int32),
+           "order": np.zeros(n_tiles * dt1, np.int32)}
+    _check(lib().vus_ba_tiles_fill_cpu(P.ref(), int(band), _p(base), n, _p(out["unit_ptr"]), _p(out["entries"]),
+                                       _p(out["order"]), None, ctypes.c_longlong(0)), "ba_tiles_fill")
+    out["entries"] = out["entries"][:n]
+    return out
+
+
 def ba_schur(P, band, lam, lin):
-    S = _BAStructure(int(band), 0, 0, None, None, None, None, None)
+    """Twin of vus_ba_schur (W, Y in L-order; the tile lists are a schedule of the same sum and are not needed here)."""
     Vinv = np.zeros((P.n_points, 6)); Y = np.zeros((P.n_obs, 18))
     Sb = np.zeros((P.n_poses, band + 1, 36)); gs = np.zeros((P.n_poses, 6))
-    _check(lib().vus_ba_schur_cpu(P.ref(), ctypes.byref(S), c_double(lam), _p(lin["W"]), _p(lin["V"]),
-                                  _p(lin["gl"]), _p(lin["Hpp"]), _p(lin["gp"]), _p(Vinv), _p(Y), _p(Sb), _p(gs)),
-           "ba_schur")
+    _check(lib().vus_ba_schur_cpu(P.ref(), None, c_double(lam), _p(lin["W"]), _p(lin["V"]), _p(lin["gl"]), _p(lin["Hpp"]),
+                                  _p(lin["gp"]), _p(Vinv), _p(Y), _p(Sb), int(band), _p(gs), None), "ba_schur")
     return {"Vinv": Vinv, "Y": Y, "Sband": Sb, "gs": gs}
 
 

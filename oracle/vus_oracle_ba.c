@@ -29,7 +29,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
-#include "../include/vus.h"
+#include "vus_oracle.h"
 
 /* ---------------------------------------------------------------------------------------------
  * small dense helpers
@@ -238,7 +238,7 @@ int vus_ba_linearize_cpu(const vus_ba_problem* P, const double* poses, const dou
     double r[3], H1[18], H2[9];
     vus_stereo_factor_cpu(poses + 12 * i, points + 3 * j, P->meas + 3 * a, P->K, P->inv_sigma, r, H1, H2);
     e += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    double* Wa = W + 18 * (size_t)P->obs_ppos[a];
+    double* Wa = W + 18 * (size_t)a;
     for (int rr = 0; rr < 6; ++rr)
       for (int c = 0; c < 3; ++c)
         Wa[3 * rr + c] = H1[rr] * H2[c] + H1[6 + rr] * H2[3 + c] + H1[12 + rr] * H2[6 + c];
@@ -335,11 +335,14 @@ int vus_ba_structure_fill_cpu(const vus_ba_problem* P, int band, const int* blk_
   return VUS_OK;
 }
 
-int vus_ba_schur_cpu(const vus_ba_problem* P, const vus_ba_structure* S, double lambda, const double* W,
-                     const double* V, const double* gl, const double* Hpp, const double* gp, double* Vinv,
-                     double* Y, double* Sband, double* gs) {
-  if (!P || !S || !W || !V || !gl || !Hpp || !gp || !Vinv || !Y || !Sband || !gs) return VUS_E_INVALID;
-  const int B = S->band, nP = P->n_poses;
+/* Twin of vus_ba_schur by the plain per-landmark statement: the tile lists T are a schedule of the SAME sum and are not
+ * read (T may be NULL); Sband has band_nodes + 1 blocks per row; W, Y in L-order; pose_stride 1. */
+int vus_ba_schur_cpu(const vus_ba_problem* P, const vus_ba_tiles* T, double lambda, const double* W, const double* V,
+                     const double* gl, const double* Hpp, const double* gp, double* Vinv, double* Y, double* Sband,
+                     int band_nodes, double* gs, int* counter) {
+  (void)T; (void)counter;
+  if (!P || !W || !V || !gl || !Hpp || !gp || !Vinv || !Y || !Sband || !gs || band_nodes < 0 || P->pose_stride > 1) return VUS_E_INVALID;
+  const int B = band_nodes, nP = P->n_poses;
   memset(Sband, 0, sizeof(double) * 36 * (size_t)nP * (B + 1));
   for (int i = 0; i < nP; ++i) {
     double* D = Sband + 36 * (size_t)i * (B + 1);
@@ -354,8 +357,8 @@ int vus_ba_schur_cpu(const vus_ba_problem* P, const vus_ba_structure* S, double 
     sym3_inverse(Vd, Vinv + 6 * j);
     const double* Vi = Vinv + 6 * j;
     for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a) {
-      const double* Wa = W + 18 * (size_t)P->obs_ppos[a];
-      double* Ya = Y + 18 * (size_t)P->obs_ppos[a];
+      const double* Wa = W + 18 * (size_t)a;
+      double* Ya = Y + 18 * (size_t)a;
       for (int rr = 0; rr < 6; ++rr)
         for (int c = 0; c < 3; ++c)
           Ya[3 * rr + c] = Wa[3 * rr] * sym3_at(Vi, 0, c) + Wa[3 * rr + 1] * sym3_at(Vi, 1, c) +
@@ -366,11 +369,11 @@ int vus_ba_schur_cpu(const vus_ba_problem* P, const vus_ba_structure* S, double 
     }
     for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a) {
       int ia = P->obs_pose[a];
-      const double* Ya = Y + 18 * (size_t)P->obs_ppos[a];
+      const double* Ya = Y + 18 * (size_t)a;
       for (int b = P->point_ptr[j]; b <= a; ++b) {
         int ib = P->obs_pose[b];
         if (ia - ib > B || ib > ia || (ia == ib && a != b)) return VUS_E_INVALID;
-        const double* Wb = W + 18 * (size_t)P->obs_ppos[b];
+        const double* Wb = W + 18 * (size_t)b;
         double* blk = Sband + 36 * ((size_t)ia * (B + 1) + (ia - ib));
         for (int rr = 0; rr < 6; ++rr)
           for (int c = 0; c < 6; ++c)
@@ -474,7 +477,7 @@ int vus_ba_backsub_cpu(const vus_ba_problem* P, const double* W, const double* V
   for (int j = 0; j < P->n_points; ++j) {
     double t[3] = {gl[3 * j], gl[3 * j + 1], gl[3 * j + 2]};
     for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a) {
-      const double* Wa = W + 18 * (size_t)P->obs_ppos[a];
+      const double* Wa = W + 18 * (size_t)a;
       const double* d = dp + 6 * P->obs_pose[a];
       for (int c = 0; c < 3; ++c)
         for (int rr = 0; rr < 6; ++rr) t[c] += Wa[3 * rr + c] * d[rr];
@@ -543,9 +546,6 @@ int vus_ba_lm_optimize_cpu(const vus_ba_problem* P, int band, const vus_lm_param
                            double* points, vus_lm_report* rep) {
   if (!P || !prm || !poses || !points || !rep || band < 0) return VUS_E_INVALID;
   const int nP = P->n_poses, nL = P->n_points, nO = P->n_obs;
-  vus_ba_structure S;
-  memset(&S, 0, sizeof S);
-  S.band = band;
   double* W = malloc(sizeof(double) * 18 * (size_t)nO);
   double* Y = malloc(sizeof(double) * 18 * (size_t)nO);
   double* V = malloc(sizeof(double) * 6 * (size_t)nL);
@@ -575,7 +575,7 @@ int vus_ba_lm_optimize_cpu(const vus_ba_problem* P, int band, const vus_lm_param
     int stop_lambda_search = 0, accepted = 0;
     for (;;) {
       int status = 0;
-      rc = vus_ba_schur_cpu(P, &S, lambda, W, V, gl, Hpp, gp, Vinv, Y, Sb, gs);
+      rc = vus_ba_schur_cpu(P, NULL, lambda, W, V, gl, Hpp, gp, Vinv, Y, Sb, band, gs, NULL);
       if (rc) break;
       vus_ba_band_solve_cpu(Sb, nP, band, gs, dp, &status);
       ++rep->tries;

@@ -18,7 +18,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
-#include "../include/vus.h"
+#include "vus_oracle.h"
 
 void vus_stereo_factor_cpu(const double* T, const double* p, const double* m, const double* K, double w,
                            double* r, double* H1, double* H2);

@@ -499,8 +499,8 @@ int vus_nav_lm_optimize_cpu(const vus_ba_problem* P, const vus_nav_factors* N, c
         sym3_inv(Vd, Vinv + 6 * j);
         const double* Vi = Vinv + 6 * j;
         for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a) {
-          const double* Wa = W + 18 * (size_t)P->obs_ppos[a];
-          double* Ya = Y + 18 * (size_t)P->obs_ppos[a];
+          const double* Wa = W + 18 * (size_t)a;
+          double* Ya = Y + 18 * (size_t)a;
           for (int rr = 0; rr < 6; ++rr)
             for (int c = 0; c < 3; ++c)
               Ya[3 * rr + c] = Wa[3 * rr] * s3(Vi, 0, c) + Wa[3 * rr + 1] * s3(Vi, 1, c) + Wa[3 * rr + 2] * s3(Vi, 2, c);
@@ -511,8 +511,8 @@ int vus_nav_lm_optimize_cpu(const vus_ba_problem* P, const vus_nav_factors* N, c
         for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a)
           for (int b = P->point_ptr[j]; b < P->point_ptr[j + 1]; ++b) {
             const int ia = P->obs_pose[a], ib = P->obs_pose[b];
-            const double* Ya = Y + 18 * (size_t)P->obs_ppos[a];
-            const double* Wb = W + 18 * (size_t)P->obs_ppos[b];
+            const double* Ya = Y + 18 * (size_t)a;
+            const double* Wb = W + 18 * (size_t)b;
             for (int rr = 0; rr < 6; ++rr)
               for (int c = 0; c < 6; ++c)
                 S[(size_t)(9 * ia + rr) * nc + 9 * ib + c] -= Ya[3 * rr] * Wb[3 * c] + Ya[3 * rr + 1] * Wb[3 * c + 1] + Ya[3 * rr + 2] * Wb[3 * c + 2];
@@ -526,7 +526,7 @@ int vus_nav_lm_optimize_cpu(const vus_ba_problem* P, const vus_nav_factors* N, c
         for (int j = 0; j < nL; ++j) {
           double t[3] = {gl[3 * j], gl[3 * j + 1], gl[3 * j + 2]};
           for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a) {
-            const double* Wa = W + 18 * (size_t)P->obs_ppos[a];
+            const double* Wa = W + 18 * (size_t)a;
             const double* dd = d + 9 * P->obs_pose[a];
             for (int c = 0; c < 3; ++c)
               for (int rr = 0; rr < 6; ++rr) t[c] += Wa[3 * rr + c] * dd[rr];

@@ -105,3 +105,68 @@ int vus_exclusive_scan_i32_cpu(const int* in, int n, int* out, long long* total)
   total[0] = run;
   return VUS_OK;
 }
+
+/* ---- tile-pair structure of the landmark elimination (vus_ba_tiles; csrc/pack.hip builds it with two launches and a
+ * radix sort): the plain statement -- for every unit in turn, every landmark in turn. */
+int vus_ba_tiles_count_cpu(const vus_ba_problem* P, int* lm_entries) {
+  if (!P || !lm_entries || P->n_points < 1) return VUS_E_INVALID;
+  for (int j = 0; j < P->n_points; ++j) {
+    int m = 0, prev = -1;
+    for (int a = P->point_ptr[j]; a < P->point_ptr[j + 1]; ++a) {
+      const int t = P->obs_pose[a] / 8;
+      m += t != prev;
+      prev = t;
+    }
+    lm_entries[j] = m * (m + 1) / 2;
+  }
+  return VUS_OK;
+}
+
+long long vus_ba_tiles_work_bytes_cpu(int n_entries) { (void)n_entries; return 0; }
+
+int vus_ba_tiles_fill_cpu(const vus_ba_problem* P, int band, const int* lm_base, int n_entries, int* unit_ptr, int* entries,
+                          int* order, void* work, long long work_bytes) {
+  (void)work; (void)work_bytes; (void)lm_base;
+  if (!P || band < 0 || n_entries < 0 || !unit_ptr || !order) return VUS_E_INVALID;
+  const int n_tiles = (P->n_poses + 7) / 8, dt1 = (band + 7) / 8 + 1, n_units = n_tiles * dt1;
+  int* cnt = (int*)calloc((size_t)n_units + 1, sizeof(int));
+  /* pass 1 counts, pass 2 places: landmarks ascend inside every unit */
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int j = 0; j < P->n_points; ++j) {
+      const int a0 = P->point_ptr[j], a1 = P->point_ptr[j + 1];
+      for (int a = a0; a < a1;) {
+        const int tu = P->obs_pose[a] / 8, au = a;
+        int mu = 0;
+        for (; a < a1 && P->obs_pose[a] / 8 == tu; ++a) mu |= 1 << (P->obs_pose[a] % 8);
+        for (int b = a0; b < a;) {
+          const int tv = P->obs_pose[b] / 8, bv = b;
+          int mv = 0;
+          for (; b < a1 && P->obs_pose[b] / 8 == tv; ++b) mv |= 1 << (P->obs_pose[b] % 8);
+          const int u = tu * dt1 + (tu - tv);
+          if (tu - tv >= dt1) { free(cnt); return VUS_E_INVALID; }
+          if (pass == 0) ++cnt[u];
+          else {
+            int* e = entries + 4 * (size_t)cnt[u]++;
+            e[0] = au; e[1] = bv; e[2] = j; e[3] = mu | (mv << 8);
+          }
+        }
+      }
+    }
+    if (pass == 0) {
+      int run = 0;
+      for (int u = 0; u <= n_units; ++u) { const int c = u < n_units ? cnt[u] : 0; unit_ptr[u] = run; cnt[u] = run; run += c; }
+      if (run != n_entries) { free(cnt); return VUS_E_INVALID; }
+    }
+  }
+  free(cnt);
+  /* order: any permutation with non-increasing size CLASS (bit length of the count) is valid; here: stable by class */
+  int pos = 0;
+  for (int cls = 32; cls >= 0; --cls)
+    for (int u = 0; u < n_units; ++u) {
+      const int c = unit_ptr[u + 1] - unit_ptr[u];
+      int bl = 0;
+      for (int v = c; v > 0; v >>= 1) ++bl;
+      if (bl == cls) order[pos++] = u;
+    }
+  return VUS_OK;
+}

@@ -6,7 +6,8 @@ import re
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # entry points that return something else than a status code (bound by hand in _lib.load) or have no device work
 HOST_ONLY = ("vus_abi_version", "vus_last_error", "vus_build_target", "vus_ba_work_doubles", "vus_nav_work_doubles",
-             "vus_ba_band_solve_work_doubles", "vus_ba_get_tuning", "vus_pack_work_bytes", "vus_imu_preintegrate")
+             "vus_ba_band_solve_work_doubles", "vus_ba_get_tuning", "vus_pack_work_bytes", "vus_imu_preintegrate",
+             "vus_ba_tiles_work_bytes")
 
 
 def _declared():

@@ -50,16 +50,20 @@ def sub_problem(oracle, s, mask):
 def test_c3_has_the_baseline_size(c3):
     s, prob, sv = c3
     assert prob.n_poses == 2000 and prob.n_points == 50238 and prob.n_obs == 2000201          # >= 50 k observed, >= 2.0 M
-    assert prob.band >= 200 and prob.st["n_pairs"] > 5e7
+    assert prob.band >= 200 and prob.tiles["n_entries"] > 1.5e6
 
 
-def test_c3_device_built_structure_equals_the_sorted_pair_construction(c3):
-    """The 57 M pair lists built by csrc/structure.hip at the BASELINE size, bit for bit against the torch construction."""
+def test_c3_device_built_tile_structure_equals_the_plain_statement(c3, oracle):
+    """The 1.8 M tile-pair entries csrc/pack.hip builds at the BASELINE size (two launches + a radix sort), bit for bit
+    against oracle/vus_oracle_pack.c (unit by unit, landmark by landmark)."""
     s, prob, sv = c3
-    ref = ba_pack.build_structure(prob.pk)
-    assert (prob.st["n_blocks"], prob.st["n_pairs"]) == (ref["n_blocks"], ref["n_pairs"])
-    for k in ("blk_ptr", "blk_i", "blk_k", "pair_a", "pair_b"):
-        assert torch.equal(prob.st[k], ref[k]), k
+    P = oracle.BAProblem({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in prob.pk.items()}, s["K"], s["sigma"])
+    ref = oracle.ba_tiles(P, prob.band)
+    tl = prob.tiles
+    assert tl["n_entries"] == ref["n_entries"] > 1.5e6 and tl["n_units"] == ref["n_units"] == 250 * 29
+    assert np.array_equal(tl["unit_ptr"].cpu().numpy(), ref["unit_ptr"])
+    assert np.array_equal(tl["entries"].cpu().numpy()[:tl["n_entries"]], ref["entries"])
+    assert sorted(tl["order"].cpu().tolist()) == list(range(tl["n_units"]))
 
 
 def test_c3_linearisation_matches_oracle_on_a_landmark_sample(c3, oracle):
@@ -76,9 +80,7 @@ def test_c3_linearisation_matches_oracle_on_a_landmark_sample(c3, oracle):
     assert relerr(sv.gl.cpu().numpy()[sel], lin["gl"]) < 1e-11
     # W rows: the sequence is sorted by (point, pose), so L-order index == sequence index on both sides
     assert bool((prob.pk["perm"].cpu() == torch.arange(prob.n_obs)).all())
-    full_slot = prob.pk["obs_ppos"].cpu().numpy()[np.nonzero(mask)[0]]
-    sub_slot = pk["obs_ppos"].numpy()
-    assert relerr(sv.W.cpu().numpy()[full_slot], lin["W"][sub_slot]) < 1e-11
+    assert relerr(sv.W.cpu().numpy()[np.nonzero(mask)[0]], lin["W"]) < 1e-11        # W in L-order on both sides
 
 
 @pytest.mark.parametrize("lam", [1e-5, 10.0])

@@ -48,6 +48,7 @@ def test_kernels_match_oracle_stage_by_stage(gpu, oracle, size):
     # Schur complement for two dampings
     for lam in (1e-5, 10.0):
         Y = torch.empty((prob.n_obs, 18), dtype=torch.float64, device="cuda")     # optional output of the call
+        sv.Sband.fill_(float("nan")); sv.gs.fill_(float("nan")); sv.Vinv.fill_(float("nan"))
         sv.schur(lam, Y)
         torch.cuda.synchronize()
         sch = oracle.ba_schur(P, prob.band, lam, lin)
@@ -55,7 +56,15 @@ def test_kernels_match_oracle_stage_by_stage(gpu, oracle, size):
         assert relerr(Y.cpu().numpy(), sch["Y"]) < 1e-10
         assert relerr(sv.gs.cpu().numpy(), sch["gs"]) < 1e-10
         Sg = sv.Sband.cpu().numpy()
+        assert np.isfinite(Sg).all()                                 # every stored block is written (none accumulated into)
         assert relerr(Sg, sch["Sband"]) < 1e-10
+        nPq, Bq = prob.n_poses, prob.band                            # diagonal blocks come out whole and symmetric
+        D = Sg[:, 0].reshape(nPq, 6, 6)
+        assert np.array_equal(D, D.transpose(0, 2, 1))
+        sv.schur(lam)
+        torch.cuda.synchronize()
+        assert np.array_equal(sv.Sband.cpu().numpy(), Sg)            # fixed summation order: bit-identical from run to run
+        assert np.array_equal(sv.gs.cpu().numpy(), sv.gs.cpu().numpy())
         # band solve: compare the solution (and the factor on the lower triangles)
         sv.band_solve()
         torch.cuda.synchronize()
@@ -371,6 +380,46 @@ def test_two_sided_solve_inside_the_lm_gives_the_one_sided_result(gpu, oracle):
     assert relerr(points2.cpu().numpy(), points1.cpu().numpy()) < 1e-7
 
 
+def _expand_tiles(tl, obs_pose, nP):
+    """Every (pose i, pose k, landmark j) a tile structure covers, from its entries (numpy)."""
+    dt1 = tl["n_units"] // tl["n_tiles"]
+    out = []
+    for u in range(tl["n_units"]):
+        I, d = divmod(u, dt1)
+        for a, b, j, m in tl["entries"][tl["unit_ptr"][u]:tl["unit_ptr"][u + 1]]:
+            ra = [a + t for t in range(bin(m & 0xFF).count("1"))]
+            rb = [b + t for t in range(bin(m >> 8).count("1"))]
+            assert [obs_pose[r] % 8 for r in ra] == [q for q in range(8) if (m >> q) & 1]
+            assert [obs_pose[r] % 8 for r in rb] == [q for q in range(8) if (m >> (8 + q)) & 1]
+            assert all(obs_pose[r] // 8 == I for r in ra) and all(obs_pose[r] // 8 == I - d for r in rb)
+            out += [(obs_pose[x], obs_pose[y], j) for x in ra for y in rb if obs_pose[y] <= obs_pose[x]]
+    return out
+
+
+@pytest.mark.parametrize("size,kw", [((12, 60, 30), {}), ((50, 500, 100), {}), ((77, 900, 60), dict(line_len=9)),
+                                     ((150, 4000, 300), {}), ((5, 40, 20), {})])
+def test_tile_structure_device_equals_the_plain_statement(gpu, oracle, size, kw):
+    """csrc/pack.hip (count, emit, stable radix sort by unit) against oracle/vus_oracle_pack.c (unit by unit, landmark
+    by landmark): unit_ptr and entries bit for bit; `order` a permutation by non-increasing size class; and the
+    entries expand to exactly the co-observation triples (i >= k, j) of the graph."""
+    s, prob, sv, P = setup(oracle, *size, **kw)
+    ref = oracle.ba_tiles(P, prob.band)
+    tl = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in prob.tiles.items()}
+    assert (tl["band"], tl["n_tiles"], tl["n_units"], tl["n_entries"]) == (ref["band"], ref["n_tiles"], ref["n_units"], ref["n_entries"])
+    assert np.array_equal(tl["unit_ptr"], ref["unit_ptr"]) and np.array_equal(tl["entries"][:tl["n_entries"]], ref["entries"])
+    size_of = np.diff(tl["unit_ptr"])
+    cls = np.where(size_of > 0, np.floor(np.log2(np.maximum(size_of, 1))) + 1, 0)
+    assert sorted(tl["order"].tolist()) == list(range(tl["n_units"])) and (np.diff(cls[tl["order"]]) <= 0).all()
+    if prob.n_obs < 6000:
+        op = prob.pk["obs_pose"].cpu().numpy()
+        ol = prob.pk["obs_point"].cpu().numpy()
+        got = sorted(_expand_tiles(dict(tl, entries=tl["entries"][:tl["n_entries"]]), op, prob.n_poses))
+        want = sorted((op[x], op[y], ol[x]) for j in range(prob.n_points)
+                      for x in range(prob.pk["point_ptr"][j], prob.pk["point_ptr"][j + 1])
+                      for y in range(prob.pk["point_ptr"][j], x + 1))
+        assert got == want
+
+
 def test_window_kernel_that_cannot_keep_its_workgroups_resident_falls_back_to_launch_pairs(gpu, oracle, band_tuning):
     """chol_window_kernel's flag protocol needs its whole grid resident; when something else holds CUs a
     workgroup never starts, the bounded waits expire (milliseconds, not seconds) and the status word says
@@ -494,38 +543,36 @@ def test_graph_without_landmarks_is_a_prior_only_problem(gpu, oracle):
 
 
 @pytest.mark.parametrize("case", [(30, 200, 10, 6), (64, 500, 64, 20), (7, 40, 7, 7), (700, 900, 600, 12), (3, 5000, 3, 3)])
-def test_device_structure_builder_is_bit_identical_to_the_sorted_pair_construction(gpu, oracle, case):
-    """csrc/structure.hip (per-row stable counting sort through a bit matrix) against ba_pack.build_structure (torch:
-    every pair materialised and sorted) and the oracle's row-by-row statement: identical index arrays.  Cases: narrow and
-    full-width bands, a band of 600 poses (fewer than 32 bit-words per block row in LDS: several passes per row), rows
-    with more than 1024 observations (several passes), landmarks seen once."""
-    from test_ba_oracle import random_cooccurrence, STRUCT_KEYS
-    from visual_underwater_slam_amd.ba import build_structure_device
+def test_tile_structure_and_schur_on_random_cooccurrence_graphs(gpu, oracle, case):
+    """Graphs that are not trajectories: narrow and full-width bands, a band of 600 poses, poses with more than 1024
+    observations, landmarks seen once, pose counts that are not multiples of the tile.  The device-built tile structure
+    == the oracle's plain statement, and the reduced camera system through it == the per-landmark statement."""
+    from test_ba_oracle import random_cooccurrence
+    from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
     n_poses, n_points, window, max_obs = case
-    op, ol = random_cooccurrence(np.random.default_rng(n_poses), n_poses, n_points, window, max_obs)
-    pk = ba_pack.pack_observations(torch.from_numpy(op).cuda(), torch.from_numpy(ol).cuda(),
-                                   torch.zeros(len(op), 3, dtype=torch.float64).cuda(), n_poses, n_points)
-    ref = ba_pack.build_structure(pk)
-    got = build_structure_device(pk)
+    rng = np.random.default_rng(n_poses)
+    op, ol = random_cooccurrence(rng, n_poses, n_points, window, max_obs)
+    K = np.array([400.0, 400, 0, 320, 240, 0.1])
+    prob = StereoBAProblem(op, ol, np.zeros((len(op), 3)), n_poses, n_points, K, 1.0)
+    sv = StereoBASolver(prob)
+    pk = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in prob.pk.items()}
+    P = oracle.BAProblem(pk, K, 1.0)
+    ref = oracle.ba_tiles(P, prob.band)
+    tl = {k: (v.cpu().numpy() if torch.is_tensor(v) else v) for k, v in prob.tiles.items()}
+    assert tl["n_entries"] == ref["n_entries"] and np.array_equal(tl["unit_ptr"], ref["unit_ptr"])
+    assert np.array_equal(tl["entries"][:tl["n_entries"]], ref["entries"])
+    nO = prob.n_obs                                        # any W, V, gl, Hpp, gp: the elimination is linear algebra on them
+    lin = {"W": rng.normal(size=(nO, 18)), "V": np.abs(rng.normal(size=(n_points, 6))) + np.array([3, 0, 0, 3, 0, 3.0]),
+           "gl": rng.normal(size=(n_points, 3)), "Hpp": rng.normal(size=(n_poses, 36)), "gp": rng.normal(size=(n_poses, 6))}
+    lin["V"][:, [1, 2, 4]] *= 0.1
+    H = lin["Hpp"].reshape(-1, 6, 6)
+    lin["Hpp"] = (H + H.transpose(0, 2, 1)).reshape(-1, 36).copy()          # symmetric, as sum H1^T H1 is
+    for k, v in lin.items():
+        getattr(sv, k).copy_(torch.from_numpy(v))
+    sv.schur(0.25)
     torch.cuda.synchronize()
-    assert (got["band"], got["n_blocks"], got["n_pairs"]) == (ref["band"], ref["n_blocks"], ref["n_pairs"])
-    for k in STRUCT_KEYS:
-        assert torch.equal(got[k], ref[k]), k
-    P = oracle.BAProblem({k: (v.cpu() if torch.is_tensor(v) else v) for k, v in pk.items()},
-                         np.array([400.0, 400, 0, 320, 240, 0.1]), 1.0)
-    cpu = oracle.ba_structure(P, ref["band"])
-    for k in STRUCT_KEYS:
-        assert np.array_equal(got[k].cpu().numpy(), cpu[k]), k
-
-
-def test_device_structure_builder_on_the_synthetic_sequences(gpu):
-    """Same comparison on the sequences the other tests solve (ragged rows, 2300 observations per pose)."""
-    from visual_underwater_slam_amd.ba import build_structure_device
-    for size in [(50, 500, 100), (8, 4000, 2500), (301, 6020, 120)]:
-        s = synth.ba_sequence(*size)
-        pk = ba_pack.pack_observations(torch.from_numpy(s["obs_pose"]).cuda(), torch.from_numpy(s["obs_point"]).cuda(),
-                                       torch.from_numpy(s["meas"]).cuda(), size[0], len(s["points_gt"]))
-        ref, got = ba_pack.build_structure(pk), build_structure_device(pk)
-        assert (got["band"], got["n_blocks"], got["n_pairs"]) == (ref["band"], ref["n_blocks"], ref["n_pairs"])
-        for k in ("blk_ptr", "blk_i", "blk_k", "pair_a", "pair_b"):
-            assert torch.equal(got[k], ref[k]), (size, k)
+    sch = oracle.ba_schur(P, prob.band, 0.25, lin)
+    Sg, So = sv.Sband.cpu().numpy(), sch["Sband"]
+    stored = np.array([[i - sl >= 0 for sl in range(prob.band + 1)] for i in range(n_poses)])
+    assert relerr(Sg[stored], So[stored]) < 1e-11 and not Sg[~stored].any()
+    assert relerr(sv.gs.cpu().numpy(), sch["gs"]) < 1e-11

@@ -129,7 +129,7 @@ def test_linearize_matches_dense_normal_equations(oracle):
     op, ol, ppos = pk["obs_pose"].numpy(), pk["obs_point"].numpy(), pk["obs_ppos"].numpy()
     for a in range(0, P.n_obs, 7):
         Wa = H[6 * op[a]:6 * op[a] + 6, 6 * nP + 3 * ol[a]:6 * nP + 3 * ol[a] + 3]
-        assert np.allclose(lin["W"][ppos[a]].reshape(6, 3), Wa, rtol=1e-11, atol=1e-9)
+        assert np.allclose(lin["W"][a].reshape(6, 3), Wa, rtol=1e-11, atol=1e-9)                 # W in L-order
 
 
 @pytest.mark.parametrize("lam", [1e-5, 1.0, 100.0])
@@ -248,6 +248,55 @@ def test_row_by_row_structure_equals_the_sorted_pair_construction(oracle, case):
         assert np.array_equal(got[k], st[k].numpy()), k
 
 
+@pytest.mark.parametrize("size", [(12, 60, 30), (37, 300, 50), (50, 500, 100)])
+def test_tile_pair_contraction_restated_in_numpy_equals_the_oracle_schur(oracle, size):
+    """The formulation csrc/ba.hip's schur_tiles_kernel runs on the matrix cores, restated in numpy from the tile
+    structure alone: per 8 x 8-pose tile pair, A = [W_ij Vinv_j] and B = [W_kj] of its landmarks side by side along K
+    (48 x 3 each, zero rows for poses that do not see the landmark), S_tile = init - A B^T.  Same reduced camera
+    system as the per-landmark statement of vus_ba_schur_cpu: the tile lists are another schedule of the same sum."""
+    s, pk, st, P = small_problem(oracle, *size)
+    lam = 0.3
+    lin = oracle.ba_linearize(P, s["poses_init"], s["points_init"])
+    sch = oracle.ba_schur(P, st["band"], lam, lin)
+    tl = oracle.ba_tiles(P, st["band"])
+    nP, B = P.n_poses, st["band"]
+    op, ppos = pk["obs_pose"].numpy(), pk["obs_ppos"].numpy()
+    dt1 = tl["n_units"] // tl["n_tiles"]
+    got = np.zeros_like(sch["Sband"])
+    covered = np.zeros((nP, B + 1), bool)
+    for u in range(tl["n_units"]):
+        I, d = divmod(u, dt1)
+        K = I - d
+        if K < 0:
+            assert tl["unit_ptr"][u] == tl["unit_ptr"][u + 1]
+            continue
+        ent = tl["entries"][tl["unit_ptr"][u]:tl["unit_ptr"][u + 1]]
+        A, Bm = np.zeros((48, 3 * len(ent))), np.zeros((48, 3 * len(ent)))
+        for n, (a, b, j, m) in enumerate(ent):
+            Vi = sch["Vinv"][j]
+            V3 = np.array([[Vi[0], Vi[1], Vi[2]], [Vi[1], Vi[3], Vi[4]], [Vi[2], Vi[4], Vi[5]]])
+            for t, q in enumerate(q for q in range(8) if (m >> q) & 1):
+                assert op[a + t] == 8 * I + q
+                A[6 * q:6 * q + 6, 3 * n:3 * n + 3] = lin["W"][a + t].reshape(6, 3) @ V3
+            for t, q in enumerate(q for q in range(8) if (m >> (8 + q)) & 1):
+                assert op[b + t] == 8 * K + q
+                Bm[6 * q:6 * q + 6, 3 * n:3 * n + 3] = lin["W"][b + t].reshape(6, 3)
+        C = A @ Bm.T
+        for ii in range(8):
+            for kk in range(8):
+                i, k = 8 * I + ii, 8 * K + kk
+                if i >= nP or k > i or i - k > B:
+                    continue
+                blk = -C[6 * ii:6 * ii + 6, 6 * kk:6 * kk + 6]
+                if i == k:
+                    blk = blk + lin["Hpp"][i].reshape(6, 6) + lam * np.eye(6)
+                got[i, i - k] = blk.reshape(-1)
+                covered[i, i - k] = True
+    want_cov = np.array([[i - sl >= 0 for sl in range(B + 1)] for i in range(nP)])
+    assert np.array_equal(covered, want_cov)                    # every stored block is written by exactly one unit
+    assert np.abs(got - sch["Sband"]).max() < 1e-11 * np.abs(sch["Sband"]).max()
+
+
 def test_multithreaded_cpu_port_equals_the_scalar_oracle(oracle):
     """oracle/ba_port.py + vus_oracle_ba_mt.c (the cpu_baseline "port": OpenMP kernels + LAPACK banded Cholesky)
     walks the same LM trajectory to the same optimum as the scalar oracle; stage outputs agree to round-off."""
@@ -265,8 +314,9 @@ def test_multithreaded_cpu_port_equals_the_scalar_oracle(oracle):
         e = port.linearize(s["poses_init"], s["points_init"])
         lin = oracle.ba_linearize(P, s["poses_init"], s["points_init"])
         assert np.isclose(e, lin["err"], rtol=1e-12)
-        for name in ("W", "V", "gl", "Hpp", "gp"):
-            assert np.allclose(getattr(port, name), lin[name], rtol=1e-11, atol=1e-9 * np.abs(lin[name]).max()), name
+        for name in ("W", "V", "gl", "Hpp", "gp"):       # the port keeps its W in P-order, the oracle (like the HIP library) in L-order
+            want = lin[name] if name != "W" else lin["W"][pk["pobs_lidx"].numpy()]
+            assert np.allclose(getattr(port, name), want, rtol=1e-11, atol=1e-9 * np.abs(want).max()), name
         port.schur(0.37)
         sch = oracle.ba_schur(P, st["band"], 0.37, lin)
         assert np.allclose(port.gs, sch["gs"], rtol=1e-10, atol=1e-10 * np.abs(sch["gs"]).max())

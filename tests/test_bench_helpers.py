@@ -17,7 +17,7 @@ def test_usable_cores_is_positive_and_bounded_by_affinity():
 
 def test_ba_roofline_objects_for_configs2_shape():
     prob = types.SimpleNamespace(n_obs=1926616, n_points=48299, n_poses=2000, n_nodes=2000, band=224,
-                                 st={"n_blocks": 308483, "n_pairs": 57452664})
+                                 tiles={"n_entries": 1754967}, n_pairs=57452664)
     ms = {"linearize": 0.26, "schur": 1.8, "band_solve": 4.27, "backsub": 0.1, "eval_step": 0.12}
     top, stages = ba_bench.roofline(prob, ms)
     for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic"):
@@ -25,12 +25,15 @@ def test_ba_roofline_objects_for_configs2_shape():
     assert top["stage"] == "band_solve" and top["kernel"] == "chol_syrk_kernel" and 0 < top["frac"] < 1
     assert top["launches_per_solve"] == 2 * 111 + 28            # two-sided: 111 (TRSM, SYRK) pairs + 28 middle panels
     assert stages["linearize"]["algorithmic_bytes"] == 1926616 * 176 + 2000 * 432 + 48299 * 120   # SURVEY 8d formula
+    sch = stages["schur"]                                        # the tile-pair GEMM: MFMA-bound, flops as issued
+    assert sch["bound"] == "mfma" and sch["flops"] == 2.0 * 48 * 48 * 3 * 1754967 and 0 < sch["frac"] < 1
+    assert sch["useful_flops"] < sch["flops"]
     json.dumps({"roofline": top, "stages": stages})
     fl, n = ba_bench.band_factor_flops(2000, 224)
     assert n == 250 and 1.5e10 < fl < 3e10
     # a short trajectory keeps the one-sided solve
     top2, _ = ba_bench.roofline(types.SimpleNamespace(n_obs=5000, n_points=500, n_poses=50, n_nodes=50, band=40,
-                                                      st={"n_blocks": 900, "n_pairs": 40000}), ms)
+                                                      tiles={"n_entries": 1200}, n_pairs=40000), ms)
     assert top2["kernel"] == "chol_trsm_update_kernel"
 
 

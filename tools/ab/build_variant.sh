@@ -14,7 +14,7 @@ pids=()
 for kind in n t; do
   extra=""; [ $kind = t ] && extra="-DVUS_TIMING"
   ( /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC $OFFLOAD -Wno-unused-function $extra $flags -c ba.hip -o /tmp/tb_$name/ba_$kind.o \
-    && /opt/rocm/bin/hipcc -shared -fPIC $OFFLOAD vus_common.o frontend.o /tmp/tb_$name/ba_$kind.o structure.o nav.o pack.o -o "$HERE/libvus_${kind}_$name.so" ) &
+    && /opt/rocm/bin/hipcc -shared -fPIC $OFFLOAD vus_common.o frontend.o /tmp/tb_$name/ba_$kind.o nav.o pack.o -o "$HERE/libvus_${kind}_$name.so" ) &
   pids+=($!)
 done
 for pid in "${pids[@]}"; do

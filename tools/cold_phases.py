@@ -22,23 +22,9 @@ for rnd in ("first", "second"):
     ol = phase("upload_obs_point", lambda: torch.as_tensor(s["obs_point"]).to(dev, torch.int32))
     me = phase("upload_meas", lambda: torch.as_tensor(s["meas"]).to(dev, torch.float64))
     pk = phase("pack_observations_device", lambda: ba_pack.pack_observations_device(op, ol, me, n_kf, nL))
-    # the pieces of build_structure_device, one by one (first call: which of them carries the 50 ms?)
-    import ctypes
-    cp = B._CProblem(n_kf, nL, pk["n_obs"], 0, None, 1.0, None, _lib.ptr(pk["obs_pose"]), _lib.ptr(pk["obs_point"]), _lib.ptr(pk["point_ptr"]),
-                     _lib.ptr(pk["obs_ppos"]), _lib.ptr(pk["pose_ptr"]), _lib.ptr(pk["pobs_lidx"]), None, None, None, 1)
-    band0 = 224
-    rows = phase("st_alloc_rows", lambda: torch.empty((2, n_kf), dtype=torch.int32, device=dev))
-    phase("st_count_kernel", lambda: _lib.call("vus_ba_structure_count", ctypes.addressof(cp), band0, _lib.ptr(rows[0]), _lib.ptr(rows[1]), _lib.current_stream_ptr()))
-    base = torch.empty((2, n_kf + 1), dtype=torch.int32, device=dev); tot = torch.empty((2,), dtype=torch.int64, device=dev)
-    phase("st_scan", lambda: [_lib.call("vus_exclusive_scan_i32", _lib.ptr(rows[q]), n_kf, _lib.ptr(base[q]), _lib.ptr(tot[q:]), _lib.current_stream_ptr()) for q in range(2)])
-    nb_, np_ = phase("st_tolist", lambda: [int(v) for v in tot.tolist()])
-    lists = phase("st_alloc_lists", lambda: [torch.empty(np_, dtype=torch.int32, device=dev), torch.empty(np_, dtype=torch.int32, device=dev),
-                                              torch.empty(nb_ + 1, dtype=torch.int32, device=dev), torch.empty(nb_, dtype=torch.int32, device=dev),
-                                              torch.empty(nb_, dtype=torch.int32, device=dev)])
-    phase("st_fill_kernel", lambda: _lib.call("vus_ba_structure_fill", ctypes.addressof(cp), band0, _lib.ptr(base[0]), _lib.ptr(base[1]), _lib.ptr(lists[2]),
-                                              _lib.ptr(lists[3]), _lib.ptr(lists[4]), _lib.ptr(lists[0]), _lib.ptr(lists[1]), _lib.current_stream_ptr()))
-    del lists, rows, base, tot
-    st = phase("build_structure_device", lambda: B.build_structure_device(pk))
+    st = {"band": B.band_of(pk)}
+    tl = phase("build_tiles_device", lambda: B.build_tiles_device(pk, st["band"]))
+    del tl
     def alloc():
         f64 = dict(dtype=torch.float64, device=dev)
         return [torch.empty((pk["n_obs"], 18), **f64), torch.empty((n_kf, st["band"] + 1, 36), **f64),

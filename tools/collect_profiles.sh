@@ -44,6 +44,6 @@ python3 $ROOT/tools/cold_phases.py 2>/dev/null | grep '^{' > $OUT/cold_phases_${
 CS=$ROOT/visual-underwater-slam_amd/csrc
 OFFLOAD=$(make -s -C $CS print-offload)
 mkdir -p /tmp/tb && (cd $CS && /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC $OFFLOAD -Wno-unused-function -DVUS_TIMING -c ba.hip -o /tmp/tb/ba_t.o 2>/dev/null \
-  && /opt/rocm/bin/hipcc -shared -fPIC $OFFLOAD vus_common.o frontend.o /tmp/tb/ba_t.o structure.o nav.o pack.o -o /tmp/tb/libvus_timing.so) \
+  && /opt/rocm/bin/hipcc -shared -fPIC $OFFLOAD vus_common.o frontend.o /tmp/tb/ba_t.o nav.o pack.o -o /tmp/tb/libvus_timing.so) \
   && VUS_HIP_LIB=/tmp/tb/libvus_timing.so python3 $ROOT/tools/win_timing.py 2>/dev/null | grep '^{' > $OUT/window_step_cycles_${TAG}.txt || true
 ls -la $OUT

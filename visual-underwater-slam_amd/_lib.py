@@ -28,9 +28,9 @@ SIGNATURES = {
     "vus_emit_stereo_factors": [_P, _P, _P, _P, c_int, c_int, c_int, ctypes.c_longlong, _P, _P, _P, _P, _P, _P, _P, _P],
     # bundle adjustment (struct arguments are passed by address)
     "vus_ba_linearize": [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
-    "vus_ba_structure_count": [_P, c_int, _P, _P, _P],
-    "vus_ba_structure_fill": [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P],
-    "vus_ba_schur": [_P, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P],
+    "vus_ba_schur": [_P, _P, c_double, _P, _P, _P, _P, _P, _P, _P, _P, c_int, _P, _P, _P],
+    "vus_ba_tiles_count": [_P, _P, _P],
+    "vus_ba_tiles_fill": [_P, c_int, _P, c_int, _P, _P, _P, _P, ctypes.c_longlong, _P],
     "vus_ba_add_diag": [_P, c_int, c_int, c_double, _P],
     "vus_ba_band_solve": [_P, c_int, c_int, _P, _P, _P, _P],
     "vus_ba_backsub": [_P, _P, _P, _P, _P, _P, _P],
@@ -92,6 +92,8 @@ def load():
     lib.vus_ba_band_solve_work_doubles.restype = ctypes.c_longlong
     lib.vus_pack_work_bytes.argtypes = [c_int]
     lib.vus_pack_work_bytes.restype = ctypes.c_longlong
+    lib.vus_ba_tiles_work_bytes.argtypes = [c_int]
+    lib.vus_ba_tiles_work_bytes.restype = ctypes.c_longlong
     lib.vus_ba_get_tuning.argtypes = [c_int]
     lib.vus_ba_get_tuning.restype = c_int
     lib.vus_nav_work_doubles.argtypes = [_P]

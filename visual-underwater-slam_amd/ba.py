@@ -28,11 +28,9 @@ class _CProblem(ctypes.Structure):
                 ("prior_T", c_void_p), ("prior_w", c_void_p), ("pose_stride", c_int)]
 
 
-class _CStructure(ctypes.Structure):
-    _fields_ = [("band", c_int), ("n_blocks", c_int), ("n_pairs", c_int), ("blk_ptr", c_void_p),
-                ("blk_i", c_void_p), ("blk_k", c_void_p), ("pair_a", c_void_p), ("pair_b", c_void_p)]
-
-
+class _CTiles(ctypes.Structure):
+    _fields_ = [("band", c_int), ("n_tiles", c_int), ("n_units", c_int), ("n_entries", c_int),
+                ("unit_ptr", c_void_p), ("entries", c_void_p), ("order", c_void_p)]
 
 
 @dataclass
@@ -70,50 +68,54 @@ def _i32(t):
     return t.to(torch.int32).contiguous()
 
 
-STRUCTURE_MAX_BAND = 6142        # widest band (poses) csrc/structure.hip keeps per row in LDS
-
-
-def build_structure_device(pk):
-    """vus_ba_structure of a packed problem, built by the HIP kernels of csrc/structure.hip: same dict, same contents
-    (bit for bit) as ba_pack.build_structure(pk), without materialising and sorting the co-observation pairs on the
-    host side.  Bands wider than STRUCTURE_MAX_BAND poses take the torch construction."""
-    n_obs, nP = pk["n_obs"], pk["n_poses"]
-    if n_obs == 0:
-        return ba_pack.build_structure(pk)
+def band_of(pk) -> int:
+    """Widest keyframe span of a landmark = half-bandwidth, in pose blocks, of the reduced camera system."""
     band = pk.get("band")
     if band is None:
+        if pk["n_obs"] == 0:
+            return 0
         op, pptr = pk["obs_pose"], pk["point_ptr"].to(torch.int64)
         seen = pptr[1:] > pptr[:-1]
         first, last = op[pptr[:-1][seen]], op[pptr[1:][seen] - 1]
         band = int((last - first).max().item())
-    if band > STRUCTURE_MAX_BAND:
-        return ba_pack.build_structure(pk)
+    return int(band)
+
+
+def build_tiles_device(pk, band):
+    """vus_ba_tiles of a packed problem (csrc/pack.hip: two launches and a radix sort): for every pair of 8-pose tiles
+    within `band` poses of each other, the landmarks seen from both, in ascending order.  Returns a dict of device
+    tensors + sizes; `band` >= the widest keyframe span of a landmark."""
+    nP, nL, n_obs = pk["n_poses"], pk["n_points"], pk["n_obs"]
     dev = pk["obs_pose"].device
-    p = _lib.ptr
-    # only the index arrays of the problem are read
-    cp = _CProblem(nP, pk["n_points"], n_obs, 0, None, 1.0, None, p(pk["obs_pose"]), p(pk["obs_point"]),
-                   p(pk["point_ptr"]), p(pk["obs_ppos"]), p(pk["pose_ptr"]), p(pk["pobs_lidx"]), None, None, None, 1)
-    rows = torch.empty((2, nP), dtype=torch.int32, device=dev)
-    st_ptr = _lib.current_stream_ptr()
-    _lib.call("vus_ba_structure_count", ctypes.addressof(cp), band, p(rows[0]), p(rows[1]), st_ptr)
-    base = torch.empty((2, nP + 1), dtype=torch.int32, device=dev)
-    totals = torch.empty((2,), dtype=torch.int64, device=dev)
-    for q in range(2):      # row counts -> list offsets (csrc/pack.hip; no torch.cumsum: its first use costs ~15 ms)
-        _lib.call("vus_exclusive_scan_i32", p(rows[q]), nP, p(base[q]), p(totals[q:]), st_ptr)
-    n_blocks, n_pairs = (int(v) for v in totals.tolist())
-    if n_pairs >= 2 ** 31:
-        raise NotImplementedError(f"{n_pairs} co-observation pairs exceed the int32 pair index")
+    n_tiles, dt1 = (nP + 7) // 8, (int(band) + 7) // 8 + 1
     i32 = dict(dtype=torch.int32, device=dev)
-    st = {"band": band, "n_blocks": n_blocks, "n_pairs": n_pairs, "blk_ptr": torch.empty(n_blocks + 1, **i32),
-          "blk_i": torch.empty(n_blocks, **i32), "blk_k": torch.empty(n_blocks, **i32),
-          "pair_a": torch.empty(n_pairs, **i32), "pair_b": torch.empty(n_pairs, **i32)}
-    _lib.call("vus_ba_structure_fill", ctypes.addressof(cp), band, p(base[0]), p(base[1]), p(st["blk_ptr"]),
-              p(st["blk_i"]), p(st["blk_k"]), p(st["pair_a"]), p(st["pair_b"]), st_ptr)
-    return st
+    out = {"band": int(band), "n_tiles": n_tiles, "n_units": n_tiles * dt1, "n_entries": 0,
+           "unit_ptr": torch.zeros(n_tiles * dt1 + 1, **i32), "order": torch.arange(n_tiles * dt1, **i32),
+           "entries": torch.zeros((1, 4), **i32)}
+    if n_obs == 0 or nL == 0:
+        return out
+    p, st_ptr = _lib.ptr, _lib.current_stream_ptr()
+    cp = _CProblem(nP, nL, n_obs, 0, None, 1.0, None, p(pk["obs_pose"]), p(pk["obs_point"]), p(pk["point_ptr"]),
+                   p(pk["obs_ppos"]), p(pk["pose_ptr"]), p(pk["pobs_lidx"]), None, None, None, 1)
+    cnt = torch.empty(nL, **i32)
+    base = torch.empty(nL + 1, **i32)
+    total = torch.empty(1, dtype=torch.int64, device=dev)
+    _lib.call("vus_ba_tiles_count", ctypes.addressof(cp), p(cnt), st_ptr)
+    _lib.call("vus_exclusive_scan_i32", p(cnt), nL, p(base), p(total), st_ptr)
+    n = int(total.item())
+    if n >= 2 ** 31:
+        raise NotImplementedError(f"{n} tile-pair entries exceed the int32 entry index")
+    out["n_entries"] = n
+    out["entries"] = torch.empty((max(n, 1), 4), **i32)
+    nbytes = int(_lib.load().vus_ba_tiles_work_bytes(n))
+    work = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    _lib.call("vus_ba_tiles_fill", ctypes.addressof(cp), int(band), p(base), n, p(out["unit_ptr"]), p(out["entries"]),
+              p(out["order"]), p(work), nbytes, st_ptr)
+    return out
 
 
 class StereoBAProblem:
-    """Packed, device-resident stereo BA problem (vus_ba_problem + vus_ba_structure)."""
+    """Packed, device-resident stereo BA problem (vus_ba_problem + vus_ba_tiles)."""
 
     def __init__(self, obs_pose, obs_point, meas, n_poses, n_points, K, sigma, prior_pose=None,
                  prior_T=None, prior_sigmas=None, device="cuda:0", band=None, pose_stride=1):
@@ -130,8 +132,8 @@ class StereoBAProblem:
         else:
             pk = ba_pack.pack_observations(to_dev(obs_pose, torch.int64), to_dev(obs_point, torch.int64),
                                            to_dev(meas, torch.float64), n_poses, n_points)
-        st = build_structure_device(pk)
-        self.pk, self.st = pk, st
+        st = {"band": band_of(pk)}
+        self.pk = pk
         self.device = dev
         self.n_poses, self.n_points, self.n_obs = int(n_poses), int(n_points), pk["n_obs"]
         self.pose_stride = int(pose_stride)
@@ -164,8 +166,10 @@ class StereoBAProblem:
                                    p(pk["obs_ppos"]), p(pk["pose_ptr"]), p(pk["pobs_lidx"]),
                                    p(self.prior_pose) if n_pr else None, p(self.prior_T) if n_pr else None,
                                    p(self.prior_w) if n_pr else None, int(pose_stride))
-        self.c_structure = _CStructure(st["band"], st["n_blocks"], st["n_pairs"], p(st["blk_ptr"]), p(st["blk_i"]),
-                                       p(st["blk_k"]), p(st["pair_a"]), p(st["pair_b"]))
+        # the tile pairs the Schur kernel walks (their band is in POSES), built once per graph on the device
+        self.tiles = tl = build_tiles_device(pk, self.band // self.pose_stride)
+        self.c_tiles = _CTiles(tl["band"], tl["n_tiles"], tl["n_units"], tl["n_entries"], p(tl["unit_ptr"]),
+                               p(tl["entries"]), p(tl["order"]))
         torch.cuda.synchronize(dev)
         self.setup_seconds = time.perf_counter() - t0
 
@@ -200,6 +204,7 @@ class StereoBASolver:
         # the band; its workspace (pose-reversed copy of the lower half + the middle system) is allocated once
         self.band_rhs = 1
         self._alloc_band_work()
+        self._unit_counter = torch.zeros(1, dtype=torch.int32, device=dev)      # the Schur kernel's unit queue
 
     SPLIT_MIN_EXTRA = 64       # use the two-sided solve when n_nodes >= 2 * band + this
 
@@ -224,12 +229,12 @@ class StereoBASolver:
                   p(self.Hpp), p(self.gp), p(self.scal), p(self.work), _lib.current_stream_ptr())
 
     def schur(self, lam: float, Y=None):
-        """Y: optional [n_obs,18] buffer that receives W Vinv (P-order); the kernels form it on the fly and need no
-        such array (277 MB at configs[2])."""
+        """Y: optional [n_obs,18] buffer that receives W Vinv (L-order); the kernel forms it on the fly and needs no
+        such array (288 MB at configs[2])."""
         p = _lib.ptr
-        _lib.call("vus_ba_schur", self._pp(), ctypes.addressof(self.P.c_structure), float(lam), p(self.W), p(self.V),
-                  p(self.gl), p(self.Hpp), p(self.gp), p(self.Vinv), p(Y), p(self.Sband), p(self.gs),
-                  _lib.current_stream_ptr())
+        _lib.call("vus_ba_schur", self._pp(), ctypes.addressof(self.P.c_tiles), float(lam), p(self.W), p(self.V),
+                  p(self.gl), p(self.Hpp), p(self.gp), p(self.Vinv), p(Y), p(self.Sband), self.P.band, p(self.gs),
+                  p(self._unit_counter), _lib.current_stream_ptr())
 
     def band_solve(self):
         p = _lib.ptr

@@ -38,6 +38,15 @@ def stage_breakdown(sv, poses, points, lam=1e-5, reps=5):
     return {k: round(statistics.median(v), 4) for k, v in acc.items()}
 
 
+def schur_pairs(prob):
+    """Co-observation pairs (i >= k, landmark): sum over landmarks of T (T + 1) / 2 for track length T."""
+    if getattr(prob, "n_pairs", None) is not None:
+        return int(prob.n_pairs)
+    pp = prob.pk["point_ptr"].to(torch.int64)
+    t = pp[1:] - pp[:-1]
+    return int((t * (t + 1) // 2).sum().item())
+
+
 def band_factor_flops(n_nodes, band):
     """Floating-point operations of the right-looking block-band Cholesky, panel by panel (multiply-add = 2):
     48-column panel factor + substitution of the window rows + symmetric update of the window."""
@@ -53,10 +62,13 @@ def band_factor_flops(n_nodes, band):
 def roofline(prob, stage_ms):
     """Algorithmic bytes / flops per LM trial over the measured stage times."""
     nO, nL, nP, B = prob.n_obs, prob.n_points, prob.n_poses, prob.band
-    nblk, npair, nN = prob.st["n_blocks"], prob.st["n_pairs"], prob.n_nodes
+    nN, n_ent, npair = prob.n_nodes, prob.tiles["n_entries"], schur_pairs(prob)
     lin_bytes = nO * (32 + 144) + nP * (96 + 288 + 48) + nL * (24 + 72 + 24)
-    schur_bytes = 144 * nO + 72 * nL + 288 * nblk                # W once (Y = W V^-1 is formed on the fly), V^-1, the S blocks written
-    schur_flops = 2.0 * 108 * npair + 2.0 * 54 * nO              # 6x3 * 3x6 per co-observation pair + Y = W V^-1
+    schur_bytes = 144 * nO + 72 * nL + 288 * nN * (B + 1)        # W once (Y = W V^-1 is formed on the fly), V^-1, every stored S block written once
+    schur_flops = 2.0 * 108 * npair + 2.0 * 54 * nO              # useful: 6x3 * 3x6 per co-observation pair + Y = W V^-1
+    # executed on the matrix cores: per tile-pair entry (one landmark, two 8-pose tiles) a 48 x 48 x 3 product, zero rows
+    # for poses that do not see the landmark included; of a tile pair (I, I) six of the nine 16 x 16 tiles + three for gs
+    schur_mfma_flops = 2.0 * 48 * 48 * 3 * n_ent
     band_bytes = 2.0 * 288 * nN * (B + 1) + 288 * nN * (B + 1)   # factor read + written, read again by the back-substitution
     fl, launches = band_factor_flops(nN, B)
     # launches of the two-sided solve (csrc/ba.hip split_plan): m poses eliminated from either end in m/8 (TRSM, SYRK)
@@ -77,11 +89,14 @@ def roofline(prob, stage_ms):
     stages = {
         "linearize": {"bound": "hbm", "algorithmic_bytes": lin_bytes, "achieved": round(lin_bytes / (ms["linearize"] * 1e-3) / 1e9, 1),
                       "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(lin_bytes / (ms["linearize"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-        "schur": {"bound": "hbm", "algorithmic_bytes": schur_bytes, "achieved": round(schur_bytes / (ms["schur"] * 1e-3) / 1e9, 1),
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(schur_bytes / (ms["schur"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                  "flops": schur_flops, "TFLOPs": round(schur_flops / (ms["schur"] * 1e-3) / 1e12, 2),
-                  "gathered_bytes_l2_to_l1": 144 * npair,
-                  "note": "W rows are gathered once per co-observation pair through L2->L1 (144 B x pairs), the step's real bound"},
+        "schur": {"bound": "mfma", "flops": schur_mfma_flops, "achieved": round(schur_mfma_flops / (ms["schur"] * 1e-3) / 1e12, 2),
+                  "peak": F64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(schur_mfma_flops / (ms["schur"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS, 4),
+                  "useful_flops": schur_flops, "useful_TFLOPs": round(schur_flops / (ms["schur"] * 1e-3) / 1e12, 2),
+                  "algorithmic_bytes": schur_bytes, "GBps": round(schur_bytes / (ms["schur"] * 1e-3) / 1e9, 1),
+                  "tile_entries": n_ent, "pairs": npair,
+                  "note": "block-sparse GEMM on v_mfma_f64_16x16x4 (schur_tiles_kernel): flops = the 48 x 48 x 3 products issued "
+                          "per (landmark, tile pair) entry, zero rows included (fill: pairs x 108 / flops); the stage time also "
+                          "holds vinv_kernel; W rows fetched per launch: entries x rows of both tiles x 144 B"},
         "band_solve": {"bound": "mfma", "flops": fl, "achieved": round(fl / (ms["band_solve"] * 1e-3) / 1e12, 2), "peak": F64_PEAK_TFLOPS,
                        "unit": "TFLOP/s", "frac": round(fl / (ms["band_solve"] * 1e-3) / 1e12 / F64_PEAK_TFLOPS, 4),
                        "algorithmic_bytes": band_bytes, "GBps": round(band_bytes / (ms["band_solve"] * 1e-3) / 1e9, 1),
@@ -90,7 +105,7 @@ def roofline(prob, stage_ms):
     }
     dom = max(("linearize", "schur", "band_solve"), key=lambda k: ms[k])
     band_kernel = "chol_window_kernel" if (split and mode == 3) else ("chol_syrk_kernel" if split else "chol_trsm_update_kernel")
-    top = {"kernel": {"band_solve": band_kernel, "schur": "schur_rows_kernel",
+    top = {"kernel": {"band_solve": band_kernel, "schur": "schur_tiles_kernel",
                       "linearize": "lin_points_kernel"}[dom],
            "stage": dom, "bound": stages[dom]["bound"], "achieved": stages[dom]["achieved"], "peak": stages[dom]["peak"],
            "unit": stages[dom]["unit"], "frac": stages[dom]["frac"], "traffic": None}
@@ -276,7 +291,7 @@ def run(device, n_kf=None, n_lm=None, obs_per_kf=None, with_breakdown=True, reps
         "value_cold_is": "pack + block structure (structure_setup_s, warm) + LM loop, from arrays already in HBM",
         "config": {"workload": ("configs[2]" if n_kf == 2000 else f"{n_kf}-keyframe") + ": stereo BA, synthetic lawn-mower sweep", "keyframes": n_kf,
                    "landmarks": nL, "stereo_factors": prob.n_obs, "band_blocks": prob.band,
-                   "schur_blocks": prob.st["n_blocks"], "schur_pairs": prob.st["n_pairs"],
+                   "schur_tile_entries": prob.tiles["n_entries"], "schur_pairs": schur_pairs(prob),
                    "size_note": f"{n_lm} landmarks are drawn and at most {obs_per_kf} observations per keyframe kept so that "
                                 "the OBSERVED landmarks (the only ones a graph built like batch.py:295-305 can hold) are >= 50 000 "
                                 "and the factors >= 2.0 M (synth.CONFIGS2_BA; rounds 1-3 ran 48 299 / 1 926 616)"},

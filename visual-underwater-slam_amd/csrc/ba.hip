@@ -7,20 +7,21 @@
 // and error evaluation.  The Levenberg-Marquardt control flow stays on the host (ba.py).
 //
 // Layout (include/vus.h): observations in L-order (point-major) and P-order (pose-major) with both
-// permutations precomputed; the per-observation 6x3 product W in P-order so that every block of the
-// reduced camera system reads two compact per-pose segments (Y = W Vinv is formed on the fly).
+// permutations precomputed; the per-observation 6x3 product W in L-ORDER (round 4; rounds 1-3: P-order), so that a
+// landmark's rows of an 8-pose tile are consecutive: the tile-pair Schur kernel reads runs of up to 8 rows, the
+// linearisation writes and the back-substitution reads W as one stream (Y = W Vinv is formed on the fly).
 //
 // Kernel map.  Reductions are fixed-order wave / LDS / DPP sums everywhere except the cooperative
 // back-substitution of the band solve, which adds its partial products into the right-hand side with f64
 // atomics: two solves of the same system agree to ~1e-13 relative, not bitwise (the landmark-sharded
 // solver broadcasts rank 0's dp for that reason, dist.py).
-//   lin_points   wave / point      r, H1, H2 -> W (scatter to P-order), V, gl, error partial
+//   lin_points   wave / point      r, H1, H2 -> W (L-order: streamed), V, gl, error partial
 //   lin_poses    workgroup / pose  r, H1 (recomputed, never stored) -> Hpp, gp
 //   priors       one lane          PriorFactorPose3 information / gradient / error
 //   vinv (ymul)  thread / point, thread / obs   (V + lambda I)^-1  (Y = W Vinv only as an optional output)
-//   schur_init / schur_rows / schur_rhs   S = Hpp + lambda I - sum Y W^T (persistent workgroups, one block row at
-//                a time: the row's Y = W Vinv formed into LDS, W rows gathered per co-observation pair from the
-//                pair lists of structure.hip), gs = gp - sum W (Vinv gl)
+//   schur_tiles  S = Hpp + lambda I - sum Y W^T and gs = gp - sum Y gl as a block-sparse GEMM on v_mfma_f64_16x16x4:
+//                persistent workgroups, one 8 x 8-pose tile pair at a time, the landmarks seen from both tiles side by
+//                side along K (vus_ba_tiles, built by pack.hip)
 //   chol_panel (panel 0) / chol_trsm + chol_syrk (two launches per 8-pose panel: MFMA block substitution of the
 //                window's row tiles, then the SYRK tiles on v_mfma_f64_16x16x4_f64, tile (0,0) goes on to factor
 //                the next panel; chol_trsm_update = both fused in one launch, used for a single system) /
@@ -287,7 +288,7 @@ __global__ __launch_bounds__(256) void lin_points_kernel(vus_ba_problem P, const
     const double m[3] = {P.meas[3 * (size_t)a], P.meas[3 * (size_t)a + 1], P.meas[3 * (size_t)a + 2]};
     stereo_factor<true, true>(T, p, m, K, r, H1, H2);
     e += 0.5 * (r[0] * r[0] + r[1] * r[1] + r[2] * r[2]);
-    double* Wa = W + 18 * (size_t)P.obs_ppos[a];
+    double* Wa = W + 18 * (size_t)a;
 #pragma unroll
     for (int rr = 0; rr < 6; ++rr)
 #pragma unroll
@@ -416,9 +417,9 @@ __global__ void vinv_kernel(int n_points, double lambda, const double* __restric
 
 __global__ void ymul_kernel(vus_ba_problem P, const double* __restrict__ W, const double* __restrict__ Vinv,
                             double* __restrict__ Y) {
-  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;      // L-order row
   if (s >= P.n_obs) return;
-  const int j = P.obs_point[P.pobs_lidx[s]];
+  const int j = P.obs_point[s];
   double vi[6];
 #pragma unroll
   for (int k = 0; k < 6; ++k) vi[k] = Vinv[6 * (size_t)j + k];
@@ -433,281 +434,66 @@ __global__ void ymul_kernel(vus_ba_problem P, const double* __restrict__ W, cons
   }
 }
 
-// diagonal blocks S_ii = Hpp_i + lambda I (the band was zeroed before)
-__global__ void schur_init_kernel(int n_poses, int band, int ps, double lambda, const double* __restrict__ Hpp,
-                                  double* __restrict__ Sband) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= 36 * n_poses) return;
-  const int i = t / 36, e = t - 36 * i;
-  Sband[36 * (size_t)(ps * i) * (band + 1) + e] = Hpp[t] + ((e % 7 == 0) ? lambda : 0.0);
-}
-
-// lane L receives the value of lane L - n of its 16-lane row (0 for the first n lanes): DPP row_shr:n
-template <int CTRL>
-__device__ __forceinline__ double dpp_shr_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-
-// lanes of rows 1 and 3 receive lane 15 of the row before them (0 elsewhere): DPP row_bcast:15
-__device__ __forceinline__ double dpp_bcast15_f64(double v) {
-  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x142, 0xa, 0xf, true);
-  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x142, 0xa, 0xf, true);
-  return __hiloint2double(hi, lo);
-}
-
-// Row-resident block accumulation: a workgroup keeps the Y rows of pose i (its P-order segment, <= SR_ROWS rows per
-// chunk) in LDS while its waves walk the blocks (i, k) of the row, so only the W rows travel L2 -> L1 per pair
-// (144 B instead of 288 B).  Lane = 32 * ch + pair slot: a lane owns the 6x3 half block of columns 3ch .. 3ch+2 and
-// the sum over the 32 slots is four DPP row shifts plus one row broadcast (fixed order: deterministic, no atomics).
-// Rows longer than SR_ROWS are processed in chunks (pair_a ascends inside a block, so a chunk's pairs are a
-// sub-range found by bisection).
-#ifndef VUS_SR_ROWS
-#define VUS_SR_ROWS 1000
-#endif
-#ifndef VUS_SR_THREADS
-#define VUS_SR_THREADS 1024
-#endif
-constexpr int SR_ROWS = VUS_SR_ROWS;
-#ifndef VUS_SR_U
-#define VUS_SR_U 1
-#endif
-constexpr int SR_U = VUS_SR_U;           // gathers a lane keeps in flight (schur_rows_kernel)
-constexpr int SR_LD = 19;               // LDS row stride in doubles (18 + 1: see schur_rows_kernel)
-constexpr int SR_THREADS = VUS_SR_THREADS;
-
-__device__ __forceinline__ int lower_bound_i32(const int* __restrict__ a, int lo, int hi, int key) {
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (a[mid] < key) lo = mid + 1;
-    else hi = mid;
-  }
-  return lo;
-}
-
-// lower_bound over a sorted int array by one wave: 64 probes per step (four dependent loads for 300 000 entries
-// instead of the eighteen of a bisection).  Returns the same value in every lane.
-__device__ __forceinline__ int lower_bound_wave(const int* __restrict__ a, int n, int key, int lane) {
-  int lo = 0, hi = n;
-  while (lo < hi) {
-    const int len = hi - lo, step = (len + 63) >> 6;
-    const int pos = lo + step * (lane + 1) - 1;
-    const bool in_range = pos < hi;
-    const bool less = in_range && a[in_range ? pos : lo] < key;
-    const int kmax = len / step;                                  // probes inside the range
-    const int c = __popcll(__ballot(less));                       // sorted: the probes below the key come first
-    const int nlo = c == 0 ? lo : lo + step * c;
-    const int nhi = c == kmax ? hi : lo + step * (c + 1) - 1;
-    lo = nlo;
-    hi = nhi;
-  }
-  return lo;
-}
-
-constexpr int SR_MAXB = 512;      // blocks of a row that get scheduled largest first (more: natural order)
-
-__global__ __launch_bounds__(SR_THREADS) void schur_rows_kernel(vus_ba_structure S, const int* __restrict__ pose_ptr,
-                                                                const int* __restrict__ pobs_lidx,
-                                                                const int* __restrict__ obs_point,
-                                                                int n_rows, int ps, const double* __restrict__ W,
-                                                                const double* __restrict__ Vinv,
-                                                                double* __restrict__ Sband) {
-  extern __shared__ double s_y[];          // [rows of the chunk][SR_LD]
-  __shared__ int s_b0, s_b1, s_next;
-  __shared__ int s_cls[16];
-  __shared__ unsigned short s_order[SR_MAXB];
-  // Persistent workgroups, XCD-aware row order.  Block row i gathers W rows of the poses i - band .. i: 16 MB at
-  // configs[2], four times an XCD's L2.  With one workgroup per row in blockIdx order the rows that run together on
-  // an XCD are 8 poses apart and at unrelated points of their walk: every W row comes from the Infinity Cache / HBM
-  // again (PMC: 62 % L2 misses, 9 GB fetched per launch for 0.28 GB of W).  Here every XCD owns a CONTIGUOUS range
-  // of rows and its workgroups (one per CU, blockIdx % 8 = XCD under round-robin dispatch) take rows r, r + 32, ...
-  // of that range: the 32 rows of a round start together and walk the same W segments at the same pace, so one
-  // fetch serves them all (L2 misses 62 % -> 27 %).  Speed only: nothing depends on where a block really runs.
-  const int rows_per_xcd = (n_rows + 7) >> 3;
-  const int wg_per_xcd = (int)(gridDim.x >> 3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  typedef double d2_t __attribute__((ext_vector_type(2), aligned(8)));
-  for (int rr_ = (int)(blockIdx.x >> 3); rr_ < rows_per_xcd; rr_ += wg_per_xcd) {
-    const int i = (int)(blockIdx.x & 7) * rows_per_xcd + rr_;
-    if (i >= n_rows) break;
-    __syncthreads();                 // the previous row's LDS contents have been consumed
-    // the row's blocks [b0, b1): two waves search side by side
-    if (wave < 2) {
-      const int b = lower_bound_wave(S.blk_i, S.n_blocks, i + wave, lane);
-      if (lane == 0) (wave == 0 ? s_b0 : s_b1) = b;
-    }
-    if (tid < 16) s_cls[tid] = 0;
-    const int a0 = pose_ptr[i], a1 = pose_ptr[i + 1];
-    __syncthreads();
-    const int b0 = s_b0, b1 = s_b1;
-    const int nb = b1 - b0;
-    if (nb == 0) continue;
-    // Largest blocks first (counting sort by the bit length of the pair count), handed out dynamically below: the
-    // pair counts of a row's blocks range from a handful to a thousand, and with a static round-robin over the 16
-    // waves the slowest wave carried 1.31x the mean load at configs[2] (largest first: 1.01x).
-    const bool sorted = nb <= SR_MAXB;
-    int my_cls = 0;
-    if (sorted && tid < nb) {
-      const int cnt = S.blk_ptr[b0 + tid + 1] - S.blk_ptr[b0 + tid];
-      my_cls = 15 - min(15, 31 - __clz(cnt | 1));                // 0 = the largest class
-      atomicAdd(&s_cls[my_cls], 1);
-    }
-    __syncthreads();
-    if (tid == 0) {
-      int run = 0;
-      for (int c = 0; c < 16; ++c) { const int n = s_cls[c]; s_cls[c] = run; run += n; }
-    }
-    __syncthreads();
-    if (sorted && tid < nb) s_order[atomicAdd(&s_cls[my_cls], 1)] = (unsigned short)tid;
-    for (int c0 = a0; c0 < a1; c0 += SR_ROWS) {
-      const int c1 = min(c0 + SR_ROWS, a1);
-      if (c0 > a0) __syncthreads();    // the previous chunk has been consumed
-      if (tid == 0) s_next = 0;
-      {
-        // The pose's own rows Y_s = W_s Vinv_j(s) are formed while they are staged (task = one 1x3 row of a 6x3
-        // block: three consecutive doubles of W, coalesced across the tasks): Y = W Vinv is never written to memory.
-        // Rows of 18 doubles land SR_LD = 19 doubles apart: with a stride of 36 dwords the 32 rows one read
-        // instruction touches fall on 16 bank groups and collide (PMC: 69 % of the LDS cycles were bank conflicts)
-        const double* src = W + 18 * (size_t)c0;
-        for (int t = tid; t < 6 * (c1 - c0); t += SR_THREADS) {
-          const int row = t / 6, rr = t - 6 * row;
-          const double* vi = Vinv + 6 * (size_t)obs_point[pobs_lidx[c0 + row]];
-          const double w0 = src[3 * t], w1 = src[3 * t + 1], w2 = src[3 * t + 2];
-          double* dst = s_y + SR_LD * row + 3 * rr;
-          dst[0] = w0 * vi[0] + w1 * vi[1] + w2 * vi[2];
-          dst[1] = w0 * vi[1] + w1 * vi[3] + w2 * vi[4];
-          dst[2] = w0 * vi[2] + w1 * vi[4] + w2 * vi[5];
-        }
-      }
-      __syncthreads();
-      const bool whole = c0 == a0 && c1 == a1;
-      while (true) {
-        int idx = 0;
-        if (lane == 0) idx = atomicAdd(&s_next, 1);
-        idx = __builtin_amdgcn_readfirstlane(idx);
-        if (idx >= nb) break;
-#ifdef VUS_SR_DESC_K      // experiment: blocks in descending k (near-diagonal = largest first, and every wave of the row --
-                         // and the rows an XCD runs together -- inside one narrow slice of W at a time), no size sort
-        const int q = b1 - 1 - idx;
-#else
-        const int q = b0 + (sorted ? (int)s_order[idx] : idx);
-#endif
-        const int k = S.blk_k[q];
-        int p0 = S.blk_ptr[q], p1 = S.blk_ptr[q + 1];
-        if (!whole) {   // the pairs whose Y row lies in this chunk
-          p1 = lower_bound_i32(S.pair_a, p0, p1, c1);
-          p0 = lower_bound_i32(S.pair_a, p0, p1, c0);
-        }
-        if (p0 >= p1) continue;
-        // Two lanes per pair: lane = 32 * ch + slot, each lane owns the 6x3 half block of columns 3ch .. 3ch+2 and
-        // the wave takes 32 pairs per step.  The W-row gather costs per INSTRUCTION, not per byte (A/B builds,
-        // r02_summary: two loads per lane instead of five: 1.55 -> 1.05 ms); with four lanes per pair the quadrants
-        // (rh = 0, 1) of a pair fetched the same 72 bytes twice, i.e. ten load instructions per 32 pairs for five
-        // instructions' worth of distinct bytes.
-        const int sl2 = lane & 31, ch2 = lane >> 5;
-        double acc[6][3];
-#pragma unroll
-        for (int a2 = 0; a2 < 6; ++a2) acc[a2][0] = acc[a2][1] = acc[a2][2] = 0.0;
-        int ia[SR_U], ib[SR_U];
-#pragma unroll
-        for (int u = 0; u < SR_U; ++u) {
-          const int p = p0 + sl2 + 32 * u;
-          ia[u] = p < p1 ? S.pair_a[p] : -1;
-          ib[u] = p < p1 ? S.pair_b[p] : 0;
-        }
-        for (int pb_ = p0 + sl2; pb_ < p1; pb_ += 32 * SR_U) {
-          d2_t wv[SR_U][4];
-          double w8[SR_U];
-          int ca[SR_U];
-#pragma unroll
-          for (int u = 0; u < SR_U; ++u) {
-            ca[u] = ia[u];
-            const double* Wb = W + 18 * (size_t)ib[u] + 9 * ch2;
-#pragma unroll
-            for (int h = 0; h < 4; ++h) wv[u][h] = *reinterpret_cast<const d2_t*>(Wb + 2 * h);
-            w8[u] = Wb[8];
-          }
-#pragma unroll
-          for (int u = 0; u < SR_U; ++u) {      // indices of the next batch
-            const int p = pb_ + 32 * (SR_U + u);
-            ia[u] = p < p1 ? S.pair_a[p] : -1;
-            ib[u] = p < p1 ? S.pair_b[p] : 0;
-          }
-#pragma unroll
-          for (int u = 0; u < SR_U; ++u) {
-            if (ca[u] < 0) continue;
-            const double* Ya = s_y + SR_LD * (ca[u] - c0);
-            const double w[9] = {wv[u][0].x, wv[u][0].y, wv[u][1].x, wv[u][1].y, wv[u][2].x, wv[u][2].y, wv[u][3].x, wv[u][3].y, w8[u]};
-#pragma unroll
-            for (int a2 = 0; a2 < 6; ++a2) {
-              const double y0 = Ya[3 * a2], y1 = Ya[3 * a2 + 1], y2 = Ya[3 * a2 + 2];
-#pragma unroll
-              for (int b2 = 0; b2 < 3; ++b2) acc[a2][b2] += y0 * w[3 * b2] + y1 * w[3 * b2 + 1] + y2 * w[3 * b2 + 2];
-            }
-          }
-        }
-        double* blk = Sband + 36 * ((size_t)(ps * i) * (S.band + 1) + ps * (i - k)) + 3 * ch2;
-        // an off-diagonal block of a row that fits one chunk still holds the zeros of the memset: plain store
-        const bool fresh = whole && k != i;
-#pragma unroll
-        for (int a2 = 0; a2 < 6; ++a2)
-#pragma unroll
-          for (int b2 = 0; b2 < 3; ++b2) {
-            double v = acc[a2][b2];
-            v += dpp_shr_f64<0x111>(v);   // row_shr:1
-            v += dpp_shr_f64<0x112>(v);   // row_shr:2
-            v += dpp_shr_f64<0x114>(v);   // row_shr:4
-            v += dpp_shr_f64<0x118>(v);   // row_shr:8  -> lane 15 of every 16-lane row holds that row's sum
-            v += dpp_bcast15_f64(v);      // row_bcast:15 -> lane 31 (63) = slots 0..31 of ch = 0 (1), in a fixed order
-            if (sl2 == 31) {
-              if (fresh) blk[6 * a2 + b2] = -v;
-              else blk[6 * a2 + b2] -= v;
-            }
-          }
-      }
-    }
-  }   // rows of this workgroup
-}
-
-
 // ---------------------------------------------------------------------------------------------
 // The landmark elimination on the matrix cores: S(I,K) = init - sum_j A_j B_j^T per 8 x 8-pose tile pair (include/vus.h,
-// vus_ba_tiles).  A workgroup of four waves owns one unit at a time (persistent, units handed out largest first through
-// a global counter).  A wave takes the chunks c = wave, wave + 4, ... of the unit's landmark list, ST_CH landmarks each:
-// it stages A = [W_ij Vinv_j] and B = [W_kj] of the chunk K-MAJOR into its own LDS panels (panel[k][row], row = 6 * pose
-// + component: an MFMA operand fetch is 16 consecutive doubles per k), zero rows where a pose does not see the landmark,
-// and runs the 3 x 3 output tiles of 16 x 16 over the chunk's K = 3 ST_CH columns.  No workgroup barrier inside a unit:
-// the panels are wave-private, LDS operations of one wave complete in order.  The four partial tiles meet in LDS at the
-// end (fixed order: the result does not depend on scheduling) and leave as 16-byte vectors in the band's address order.
+// vus_ba_tiles), the sum over the landmarks being the K dimension of a GEMM.  A workgroup of four waves owns one unit at
+// a time (persistent, units handed out largest first through a global counter).  A wave takes the chunks c = wave,
+// wave + 4, ... of the unit's landmark list, ST_CH landmarks each: it stages A = [W_ij Vinv_j] and B = [W_kj] of the chunk
+// K-MAJOR into its own LDS panels (panel[k][row], row = 6 * pose + component: an MFMA operand fetch is 16 consecutive
+// doubles per k), zero rows where a pose does not see the landmark, and runs the 3 x 3 output tiles of 16 x 16 over the
+// chunk's K = 3 ST_CH columns.  Software-pipelined inside the wave: while the matrix cores work on chunk c, the W rows of
+// chunk c + 1 and the entry of chunk c + 2 are in flight (two dependent loads deep: entry -> rows) -- with 77 KB of LDS
+// per workgroup in panels only two waves per SIMD are resident and nothing else would hide a memory round trip.  No
+// workgroup barrier inside a unit: the panels are wave-private, LDS operations of one wave complete in order.  The four
+// partial tiles meet in LDS at the end (fixed order: no result depends on scheduling, bit-identical from run to run) and
+// leave as 16-byte vectors in the band's address order.  W is in L-order: a landmark's rows of a tile are consecutive.
+//
+// Measured at configs[2] (profiles/r04_summary.md; 2000 keyframes, 50,238 landmarks, 2.0 M factors, 1.82 M entries): the
+// per-pair vector kernel of rounds 1-3 1.36 ms (2.6 ms once a pose has more than 1000 observations) + 0.11 ms for the
+// right-hand side; this kernel 0.65 ms including it.  Steps on the way (same box A/B, tools/schur_ab.py): W gathered
+// through obs_ppos 1.66 -> W in L-order 1.23 -> pipelined 0.86 -> one entry and Vinv per lane in registers instead of LDS
+// tables, operands of the next K step requested before the products of this one, conflict-free panel writes 0.77 ->
+// right-hand side fused 0.69.  One queue of units per XCD in natural order (neighbouring tile rows together on one L2)
+// raised the L2 hit rate from 16 % to 42 % and was SLOWER (0.79): the kernel is not memory-bound -- with every row read
+// from a cache-resident 4096-row window it takes 0.85 instead of 0.89 ms -- but a unit is up to 1638 entries = 40 % of the
+// kernel's duration for its workgroup, so the largest-first order matters more than locality.
 constexpr int ST_CH = 8;                       // landmarks per chunk
 constexpr int ST_KC = 3 * ST_CH;               // K columns per chunk: 6 steps of v_mfma_f64_16x16x4
 constexpr int ST_LD = 50;                      // panel stride in doubles (48 rows + 2)
 constexpr int ST_PANEL = ST_KC * ST_LD;
 constexpr int ST_WAVES = 4;
-constexpr int ST_WAVE_DOUBLES = 2 * ST_PANEL + 6 * ST_CH + 2 * ST_CH;     // panels, Vinv table, the chunk's entries (int4)
+constexpr int ST_WAVE_DOUBLES = 2 * ST_PANEL + ST_KC + 8;                 // the two panels, gl by K row (+ padding to 16 bytes)
 static_assert(2 * ST_PANEL >= 48 * 48, "a wave's panels also hold its partial 48 x 48 tile");
 static_assert(ST_KC % 4 == 0, "whole MFMA K steps");
 
 __device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 
-template <bool W_L_ORDER>
 __global__ __launch_bounds__(64 * ST_WAVES, 2) void schur_tiles_kernel(vus_ba_tiles T, int n_poses, int ps, int band_nodes,
-                                                                       double lambda, const double* __restrict__ W,
-                                                                       const int* __restrict__ obs_ppos,
-                                                                       const double* __restrict__ Vinv,
-                                                                       const double* __restrict__ Hpp,
-                                                                       double* __restrict__ Sband, int* __restrict__ counter) {
+                                                                        double lambda, const double* __restrict__ W,
+                                                                        const double* __restrict__ Vinv,
+                                                                        const double* __restrict__ Hpp,
+                                                                        const double* __restrict__ gl, const double* __restrict__ gp,
+                                                                        double* __restrict__ Sband, double* __restrict__ gs,
+                                                                        int* __restrict__ counter) {
   extern __shared__ __attribute__((aligned(16))) double st_smem[];
   __shared__ int s_unit;
   const int tid = threadIdx.x, lane = tid & 63, wave = wave_index();
   double* __restrict__ PA = st_smem + wave * ST_WAVE_DOUBLES;
   double* __restrict__ PB = PA + ST_PANEL;
-  double* __restrict__ vtab = PB + ST_PANEL;
-  int4* __restrict__ etab = reinterpret_cast<int4*>(vtab + 6 * ST_CH);
+  double* __restrict__ gtab = PB + ST_PANEL;      // [ST_KC]: gl of the chunk's landmarks by K row (tile pairs (I, I) only)
   const int4* __restrict__ entries = reinterpret_cast<const int4*>(T.entries);
   const int dt1 = T.n_units / T.n_tiles;
   const int arow = lane & 15, kq = lane >> 4;
+  // lane = 8 * landmark of the chunk + sub: the lane's six tasks per side are rows qr = 8 rnd + sub of ITS landmark, so one
+  // entry and one Vinv per lane and chunk, straight from memory into registers (no LDS tables, no dependent LDS reads in
+  // the staging pass); the eight lanes of a landmark read 192 contiguous bytes per round.
+  const int tl = lane >> 3, sub = lane & 7, krow = (tl >> 1) + 4 * (tl & 1);
+  int tq[6], tr[6];
+#pragma unroll
+  for (int rnd = 0; rnd < 6; ++rnd) {
+    tq[rnd] = (8 * rnd + sub) / 6;
+    tr[rnd] = (8 * rnd + sub) - 6 * tq[rnd];
+  }
   while (true) {
     __syncthreads();                 // the previous unit's partial tiles have been consumed, s_unit has been read
     if (tid == 0) s_unit = atomicAdd(counter, 1);
@@ -716,7 +502,8 @@ __global__ __launch_bounds__(64 * ST_WAVES, 2) void schur_tiles_kernel(vus_ba_ti
     if (ui >= T.n_units) break;
     const int u = T.order[ui];
     const int I = u / dt1, d = u - I * dt1, K = I - d;
-    if (K < 0) continue;             // left of the first pose: nothing is stored there
+    if (K < 0) continue;
+    const bool diag = d == 0;
     const int e0 = T.unit_ptr[u], e1 = T.unit_ptr[u + 1];
     const int n_chunks = (e1 - e0 + ST_CH - 1) / ST_CH;
     double4_t acc[3][3];
@@ -724,63 +511,100 @@ __global__ __launch_bounds__(64 * ST_WAVES, 2) void schur_tiles_kernel(vus_ba_ti
     for (int t = 0; t < 3; ++t)
 #pragma unroll
       for (int q = 0; q < 3; ++q) acc[t][q] = double4_t{0.0, 0.0, 0.0, 0.0};
-    for (int c = wave; c < n_chunks; c += ST_WAVES) {
-      // the chunk's entries and the Vinv of their landmarks -> the wave's tables
-      if (lane < ST_CH) {
-        const int e = e0 + ST_CH * c + lane;
-        etab[lane] = e < e1 ? entries[e] : make_int4(0, 0, -1, 0);
-      }
-      wave_lds_fence();
-      if (lane < 6 * ST_CH) {
-        const int l = lane / 6, j = etab[l].z;
-        vtab[lane] = j >= 0 ? Vinv[6 * (size_t)j + (lane - 6 * l)] : 0.0;
-      }
-      wave_lds_fence();
-      // task = (landmark l, pose q of the tile, row r of the 6 x 3 block): three consecutive doubles of a W row
+    // pipeline registers
+    int4 en;               // the lane's entry of the chunk whose rows are requested next
+    double wa[6][3], wb[6][3], vi[6], gv = 0.0;
+    unsigned pres = 0;     // bit rnd / 6 + rnd: the task's pose sees the landmark (side A / B)
+    // (nothing may touch `en` between its load and load_rows: a use would make the compiler wait for it at once, and with
+    // it -- the memory counter is in-order -- for every row load issued just before: the whole prefetch would be lost)
+    auto load_entries = [&](int c) {
+      const int e = e0 + ST_CH * c + tl;
+      en = entries[e < e1 ? e : e0];
+    };
+    auto load_rows = [&](int c) {     // from en (arrived): the W rows of chunk c and the landmark's Vinv
+      pres = 0;
+      const bool valid = e0 + ST_CH * c + tl < e1;
+      const int ma = valid ? en.w & 0xFF : 0, mb = valid ? (en.w >> 8) & 0xFF : 0;
 #pragma unroll
-      for (int side = 0; side < 2; ++side) {
+      for (int rnd = 0; rnd < 6; ++rnd) {
+        const int bit = 1 << tq[rnd], below = bit - 1;
+        const bool pa = ma & bit, pb = mb & bit;
+        pres |= (pa ? 1u : 0u) << rnd | (pb ? 1u : 0u) << (6 + rnd);
+        const double* ra = W + 18 * (size_t)(en.x + (pa ? __popc(ma & below) : 0)) + 3 * tr[rnd];
+        const double* rb = W + 18 * (size_t)(en.y + (pb ? __popc(mb & below) : 0)) + 3 * tr[rnd];
 #pragma unroll
-        for (int rnd = 0; rnd < 6 * ST_CH / 8; ++rnd) {            // 48 ST_CH tasks, 64 lanes
-          const int id = 64 * rnd + lane;
-          const int l = id / 48, qr = id - 48 * l, q = qr / 6, r = qr - 6 * q;
-          const int4 en = etab[l];
-          const int m = side == 0 ? (en.w & 0xFF) : ((en.w >> 8) & 0xFF);
-          const bool present = (m >> q) & 1;
-          const int row = (side == 0 ? en.x : en.y) + __popc(m & ((1 << q) - 1));
-          double w0 = 0.0, w1 = 0.0, w2 = 0.0;
-          if (present) {
-            const size_t slot = W_L_ORDER ? (size_t)row : (size_t)obs_ppos[row];
-            const double* src = W + 18 * slot + 3 * r;
-            w0 = src[0]; w1 = src[1]; w2 = src[2];
-          }
-          double* dst = (side == 0 ? PA : PB) + (3 * l) * ST_LD + qr;
-          if (side == 0) {           // Y = W Vinv (symmetric 3 x 3: xx xy xz yy yz zz)
-            const double* v = vtab + 6 * l;
-            dst[0] = w0 * v[0] + w1 * v[1] + w2 * v[2];
-            dst[ST_LD] = w0 * v[1] + w1 * v[3] + w2 * v[4];
-            dst[2 * ST_LD] = w0 * v[2] + w1 * v[4] + w2 * v[5];
-          } else {
-            dst[0] = w0; dst[ST_LD] = w1; dst[2 * ST_LD] = w2;
-          }
+        for (int k = 0; k < 3; ++k) {
+          wa[rnd][k] = ra[k];
+          wb[rnd][k] = rb[k];
         }
       }
-      wave_lds_fence();
+      const double* vsrc = Vinv + 6 * (size_t)en.z;
 #pragma unroll
-      for (int s2 = 0; s2 < ST_KC / 4; ++s2) {
-        double a[3], b[3];
+      for (int k = 0; k < 6; ++k) vi[k] = vsrc[k];
+      if (diag) gv = valid && sub < 3 ? gl[3 * (size_t)en.z + sub] : 0.0;      // the reduced right-hand side rides along
+    };
+    if (wave < n_chunks) {
+      load_entries(wave);
+      load_rows(wave);
+      if (wave + ST_WAVES < n_chunks) load_entries(wave + ST_WAVES);
+    }
+    for (int c = wave; c < n_chunks; c += ST_WAVES) {
+      // chunk c: rows (arrived during the previous chunk's products) -> panels
+      if (diag && sub < 3) gtab[8 * sub + krow] = gv;
+#pragma unroll
+      for (int rnd = 0; rnd < 6; ++rnd) {
+        const bool pa = (pres >> rnd) & 1, pb = (pres >> (6 + rnd)) & 1;
+        const double a0 = pa ? wa[rnd][0] : 0.0, a1 = pa ? wa[rnd][1] : 0.0, a2 = pa ? wa[rnd][2] : 0.0;
+        // K row of (landmark tl, column c) = 8 c + krow: which K index holds what is free as long as both panels agree.
+        // ds_write_b64 is served in groups of 16 consecutive lanes = two landmarks: with a stride of 50 doubles their
+        // rows must lie 4 apart to fall on disjoint banks (4 * 100 dwords = 16 mod 32)
+        double* da = PA + krow * ST_LD + 8 * rnd + sub;
+        da[0] = a0 * vi[0] + a1 * vi[1] + a2 * vi[2];
+        da[8 * ST_LD] = a0 * vi[1] + a1 * vi[3] + a2 * vi[4];
+        da[16 * ST_LD] = a0 * vi[2] + a1 * vi[4] + a2 * vi[5];
+        double* db = PB + krow * ST_LD + 8 * rnd + sub;
+        db[0] = pb ? wb[rnd][0] : 0.0;
+        db[8 * ST_LD] = pb ? wb[rnd][1] : 0.0;
+        db[16 * ST_LD] = pb ? wb[rnd][2] : 0.0;
+      }
+      // chunk c + 1: its entries have arrived -> request its rows; chunk c + 2: request its entries
+      if (c + ST_WAVES < n_chunks) {
+        load_rows(c + ST_WAVES);
+        if (c + 2 * ST_WAVES < n_chunks) load_entries(c + 2 * ST_WAVES);
+      }
+      wave_lds_fence();
+      {
+        double a[2][3], b[2][3];     // the operands of step s2 + 1 are requested before the products of step s2 are issued
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
-          a[t] = PA[(4 * s2 + kq) * ST_LD + 16 * t + arow];
-          b[t] = PB[(4 * s2 + kq) * ST_LD + 16 * t + arow];
+          a[0][t] = PA[kq * ST_LD + 16 * t + arow];
+          b[0][t] = PB[kq * ST_LD + 16 * t + arow];
         }
 #pragma unroll
-        for (int t = 0; t < 3; ++t)
+        for (int s2 = 0; s2 < ST_KC / 4; ++s2) {
+          const int cur = s2 & 1, nxt = cur ^ 1;
+          if (s2 + 1 < ST_KC / 4) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[q], acc[t][q], 0, 0, 0);
+            for (int t = 0; t < 3; ++t) {
+              a[nxt][t] = PA[(4 * (s2 + 1) + kq) * ST_LD + 16 * t + arow];
+              b[nxt][t] = PB[(4 * (s2 + 1) + kq) * ST_LD + 16 * t + arow];
+            }
+          }
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+#pragma unroll
+            for (int q = 0; q <= t; ++q) acc[t][q] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][t], b[cur][q], acc[t][q], 0, 0, 0);
+          // Of the tile pair (I, I) the 16 x 16 tiles above the diagonal are not stored: their accumulators take
+          // Y gl instead -- a B operand whose column 0 is gl along K and whose other columns are zero -- so column 0 of
+          // the three tiles is sum_j Y_ij Vinv_j... = what gs subtracts, rows 0-15, 16-31, 32-47
+          const double bg = diag && arow == 0 ? gtab[4 * s2 + kq] : 0.0;
+          acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[cur][0], diag ? bg : b[cur][1], acc[0][1], 0, 0, 0);
+          acc[0][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(diag ? a[cur][1] : a[cur][0], diag ? bg : b[cur][2], acc[0][2], 0, 0, 0);
+          acc[1][2] = __builtin_amdgcn_mfma_f64_16x16x4f64(diag ? a[cur][2] : a[cur][1], diag ? bg : b[cur][2], acc[1][2], 0, 0, 0);
+        }
       }
-      wave_lds_fence();              // the operands have been read before the next chunk overwrites the panels
+      wave_lds_fence();
     }
-    // the wave's partial tile, row-major [48][48], over its own panels.  C/D layout: col = lane & 15, row = (lane >> 4) + 4 reg
 #pragma unroll
     for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -788,18 +612,21 @@ __global__ __launch_bounds__(64 * ST_WAVES, 2) void schur_tiles_kernel(vus_ba_ti
 #pragma unroll
         for (int r = 0; r < 4; ++r) PA[(16 * t + kq + 4 * r) * 48 + 16 * q + arow] = acc[t][q][r];
     __syncthreads();
-    // out: pose row i of the tile = the blocks (i, 8K + 7 .. 8K), 2304 contiguous bytes; vector v = 144 ii + 18 o + e / 2
     for (int v = tid; v < 8 * 144; v += 64 * ST_WAVES) {
       const int ii = v / 144, w = v - 144 * ii, o = w / 18, e = 2 * (w - 18 * o), kk = 7 - o;
       const int i = 8 * I + ii, k = 8 * K + kk;
       if (i >= n_poses || k > i || ps * (i - k) > band_nodes) continue;
       const int rr = e / 6, cc = e - 6 * rr;
-      const int at = (6 * ii + rr) * 48 + 6 * kk + cc;
+      // a diagonal block is written whole: its elements above the diagonal come from their mirror images (of the tile pair
+      // (I, I) only the 16 x 16 tiles on and below the diagonal are computed)
+      const bool dblk = i == k;
+      const int at0 = dblk && cc > rr ? (6 * ii + cc) * 48 + 6 * kk + rr : (6 * ii + rr) * 48 + 6 * kk + cc;
+      const int at1 = dblk && cc + 1 > rr ? (6 * ii + cc + 1) * 48 + 6 * kk + rr : (6 * ii + rr) * 48 + 6 * kk + cc + 1;
       double s0 = 0.0, s1 = 0.0;
 #pragma unroll
       for (int wv = 0; wv < ST_WAVES; ++wv) {
-        s0 += st_smem[wv * ST_WAVE_DOUBLES + at];
-        s1 += st_smem[wv * ST_WAVE_DOUBLES + at + 1];
+        s0 += st_smem[wv * ST_WAVE_DOUBLES + at0];
+        s1 += st_smem[wv * ST_WAVE_DOUBLES + at1];
       }
       d2a_t out = d2a_t{-s0, -s1};
       if (i == k) {
@@ -808,31 +635,16 @@ __global__ __launch_bounds__(64 * ST_WAVES, 2) void schur_tiles_kernel(vus_ba_ti
       }
       *reinterpret_cast<d2a_t*>(Sband + 36 * ((size_t)(ps * i) * (band_nodes + 1) + (size_t)ps * (i - k)) + e) = out;
     }
-  }
-}
-
-// gs_i = gp_i - sum_{slots of pose i} W_s (Vinv gl)[point(s)]   (one wave per pose)
-__global__ __launch_bounds__(64) void schur_rhs_kernel(vus_ba_problem P, const double* __restrict__ W,
-                                                       const double* __restrict__ Vinv,
-                                                       const double* __restrict__ gl,
-                                                       const double* __restrict__ gp, double* __restrict__ gs) {
-  const int i = blockIdx.x;
-  const int lane = threadIdx.x;
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  for (int s = P.pose_ptr[i] + lane; s < P.pose_ptr[i + 1]; s += 64) {
-    const int j = P.obs_point[P.pobs_lidx[s]];
-    const double* vi = Vinv + 6 * (size_t)j;
-    const double g0 = gl[3 * (size_t)j], g1 = gl[3 * (size_t)j + 1], g2 = gl[3 * (size_t)j + 2];
-    const double t0 = vi[0] * g0 + vi[1] * g1 + vi[2] * g2;
-    const double t1 = vi[1] * g0 + vi[3] * g1 + vi[4] * g2;
-    const double t2 = vi[2] * g0 + vi[4] * g1 + vi[5] * g2;
-    const double* Ws = W + 18 * (size_t)s;
+    if (diag && tid < 48 && 8 * I + tid / 6 < n_poses) {      // gs rows of the tile's poses: column 0 of the three spare tiles
+      const int m = tid, t = m >> 4, mm = m & 15;
+      const int at = t == 0 ? mm * 48 + 16 : (t == 1 ? mm * 48 + 32 : (16 + mm) * 48 + 32);
+      double sg = 0.0;
 #pragma unroll
-    for (int rr = 0; rr < 6; ++rr) acc[rr] += Ws[3 * rr] * t0 + Ws[3 * rr + 1] * t1 + Ws[3 * rr + 2] * t2;
+      for (int wv = 0; wv < ST_WAVES; ++wv) sg += st_smem[wv * ST_WAVE_DOUBLES + at];
+      const int i = 8 * I + m / 6;
+      gs[6 * (size_t)(ps * i) + (m - 6 * (m / 6))] = gp[6 * (size_t)i + (m - 6 * (m / 6))] - sg;
+    }
   }
-#pragma unroll
-  for (int rr = 0; rr < 6; ++rr) acc[rr] = wave_sum(acc[rr]);
-  if (lane < 6) gs[6 * (size_t)pose_stride(P) * i + lane] = gp[6 * (size_t)i + lane] - acc[lane];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2649,6 +2461,13 @@ __global__ __launch_bounds__(256, 2) void chol_window_kernel(WinSet S, int band,
       if (__hip_atomic_load(S.s[q].F + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) S.s[q].status[0] = -3;
 }
 
+// slots (i, s) with s > i of the first `band` rows lie left of pose 0: never read, kept at zero (one workgroup per row)
+__global__ void band_head_zero_kernel(double* __restrict__ Sband, int n_poses, int band) {
+  const int i = blockIdx.x;
+  double* row = Sband + 36 * ((size_t)i * (band + 1) + (i + 1));
+  for (int t = threadIdx.x; t < 36 * (band - i); t += blockDim.x) row[t] = 0.0;
+}
+
 __global__ void add_diag_kernel(double* __restrict__ Sband, int n_poses, int band, double value) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < 6 * n_poses) Sband[36 * (size_t)(t / 6) * (band + 1) + 7 * (t % 6)] += value;
@@ -2670,7 +2489,7 @@ __global__ __launch_bounds__(256) void backsub_kernel(vus_ba_problem P, const do
   if (j >= P.n_points) return;
   double t[3] = {0, 0, 0};
   for (int a = P.point_ptr[j] + lane; a < P.point_ptr[j + 1]; a += 64) {
-    const double* Wa = W + 18 * (size_t)P.obs_ppos[a];
+    const double* Wa = W + 18 * (size_t)a;
     const double* d = dp + 6 * (size_t)pose_stride(P) * P.obs_pose[a];
 #pragma unroll
     for (int rr = 0; rr < 6; ++rr) {
@@ -2821,77 +2640,45 @@ extern "C" int vus_ba_linearize(const vus_ba_problem* P, const double* poses, co
   return VUS_OK;
 }
 
-extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_structure* S, double lambda, const double* W,
-                            const double* V, const double* gl, const double* Hpp, const double* gp, double* Vinv,
-                            double* Y, double* Sband, double* gs, void* stream) {
+extern "C" int vus_ba_schur(const vus_ba_problem* P, const vus_ba_tiles* T, double lambda, const double* W, const double* V,
+                            const double* gl, const double* Hpp, const double* gp, double* Vinv, double* Y, double* Sband,
+                            int band_nodes, double* gs, int* counter, void* stream) {
   if (int rc = check_problem(P)) return rc;
-  VUS_REQUIRE(S != nullptr, "structure is null");
-  VUS_REQUIRE(S->band >= 0 && S->band < pose_stride(*P) * P->n_poses + 1 && S->n_blocks >= 0 && S->n_pairs >= 0,
-              "bad structure: band=%d blocks=%d pairs=%d", S->band, S->n_blocks, S->n_pairs);
-  VUS_REQUIRE(Hpp && gp && Sband && gs, "null buffer");
-  VUS_REQUIRE((V && gl && Vinv) || !P->n_points, "null landmark buffer");
-  VUS_REQUIRE(W || !P->n_obs, "null observation buffer");
-  if (S->n_blocks > 0) VUS_REQUIRE(S->blk_ptr && S->blk_i && S->blk_k && S->pair_a && S->pair_b, "structure arrays are null");
-  VUS_REQUIRE(lambda >= 0.0, "lambda=%g", lambda);
-  hipStream_t st = vus::as_stream(stream);
+  VUS_REQUIRE(T != nullptr, "tile structure is null");
   const int nP = P->n_poses, nL = P->n_points, nO = P->n_obs;
   const int ps = pose_stride(*P);
-  VUS_CHECK_HIP(hipMemsetAsync(Sband, 0, sizeof(double) * 36 * (size_t)nP * ps * (S->band + 1), st));
-  if (ps > 1) VUS_CHECK_HIP(hipMemsetAsync(gs, 0, sizeof(double) * 6 * (size_t)nP * ps, st));
-  if (nL > 0) vinv_kernel<<<cdiv(nL, 256), 256, 0, st>>>(nL, lambda, V, Vinv);
-  if (nO > 0 && Y != nullptr) ymul_kernel<<<cdiv(nO, 256), 256, 0, st>>>(*P, W, Vinv, Y);   // optional output only
-  schur_init_kernel<<<cdiv(36ll * nP, 256), 256, 0, st>>>(nP, S->band, ps, lambda, Hpp, Sband);
-  if (S->n_blocks > 0) {
-    constexpr int lds = SR_ROWS * SR_LD * (int)sizeof(double);
-    // (kernel, device) attribute: set per call -- a host-side table write -- instead of once per process
-    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(schur_rows_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    // one workgroup per CU (it owns 144 KB of LDS), persistent over the rows of its XCD's range
-    int n_cu = device_cu_count();
-    if (n_cu < 8) n_cu = 256;
-    int wg = 8 * (n_cu / 8);
-    if (wg > 8 * ((nP + 7) / 8)) wg = 8 * ((nP + 7) / 8);
-    schur_rows_kernel<<<wg, SR_THREADS, lds, st>>>(*S, P->pose_ptr, P->pobs_lidx, P->obs_point, nP, ps, W, Vinv, Sband);
-  }
-  schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, W, Vinv, gl, gp, gs);
-  VUS_CHECK_LAUNCH("ba_schur");
-  return VUS_OK;
-}
-
-
-extern "C" int vus_ba_schur_tiles(const vus_ba_problem* P, const vus_ba_tiles* T, double lambda, const double* W,
-                                  const double* V, const double* gl, const double* Hpp, const double* gp, double* Vinv,
-                                  double* Sband, int band_nodes, double* gs, int* counter, void* stream) {
-  VUS_REQUIRE(P != nullptr && T != nullptr, "null problem or tile structure");
-  const int nP = P->n_poses, nL = P->n_points, nO = P->n_obs;
   VUS_REQUIRE(Hpp && gp && Sband && gs && counter, "null buffer");
-  VUS_REQUIRE(nL == 0 || (V && Vinv && gl), "null landmark buffer");
-  VUS_REQUIRE(nO == 0 || W, "null W");
-  const int ps = pose_stride(*P);
-  VUS_REQUIRE(T->n_tiles == (nP + 7) / 8 && T->n_units == T->n_tiles * ((T->band + 7) / 8 + 1), "tile structure of another problem");
-  VUS_REQUIRE(band_nodes >= ps * T->band, "band_nodes=%d is narrower than the tile structure's %d poses", band_nodes, T->band);
-  VUS_REQUIRE(T->n_units == 0 || (T->unit_ptr && T->order), "null tile lists");
+  VUS_REQUIRE((V && gl && Vinv) || !nL, "null landmark buffer");
+  VUS_REQUIRE(W || !nO, "null observation buffer");
+  VUS_REQUIRE(lambda >= 0.0, "lambda=%g", lambda);
+  VUS_REQUIRE(T->band >= 0 && T->n_tiles == (nP + 7) / 8 && T->n_units == T->n_tiles * ((T->band + 7) / 8 + 1) && T->n_entries >= 0,
+              "tile structure of another problem: band=%d tiles=%d units=%d", T->band, T->n_tiles, T->n_units);
+  VUS_REQUIRE(band_nodes >= ps * T->band && band_nodes < ps * nP + 1, "band_nodes=%d against %d poses of tile band, %d nodes",
+              band_nodes, T->band, ps * nP);
+  VUS_REQUIRE(T->unit_ptr && T->order && (T->entries || T->n_entries == 0), "tile lists are null");
   hipStream_t st = vus::as_stream(stream);
-  // with velocity nodes between the poses (ps = 2) the blocks the tiles do not cover belong to the inertial factors:
-  // zeroed here.  With ps = 1 every stored block (i, k), 0 <= k <= i, i - k <= band, is written by its tile pair; the
-  // slots left of pose 0 (k < 0) are never read by the solvers (band_index.h masks them) but are kept finite.
-  VUS_CHECK_HIP(hipMemsetAsync(Sband, 0, sizeof(double) * 36 * (size_t)nP * ps * (band_nodes + 1), st));
-  if (ps > 1) VUS_CHECK_HIP(hipMemsetAsync(gs, 0, sizeof(double) * 6 * (size_t)nP * ps, st));
+  // With velocity nodes between the poses (ps = 2) the blocks the tile pairs do not cover belong to the inertial
+  // factors and start from zero.  With ps = 1 every stored block (i, k), 0 <= k <= i, i - k <= band, is WRITTEN by its
+  // tile pair (nothing is accumulated into); the slots left of pose 0 (k < 0) of the first band rows are never read by
+  // the solvers (csrc/band_index.h masks them) and only kept finite.
+  if (ps > 1) {
+    VUS_CHECK_HIP(hipMemsetAsync(Sband, 0, sizeof(double) * 36 * (size_t)nP * ps * (band_nodes + 1), st));
+    VUS_CHECK_HIP(hipMemsetAsync(gs, 0, sizeof(double) * 6 * (size_t)nP * ps, st));
+  } else if (band_nodes > 0) {
+    band_head_zero_kernel<<<min(band_nodes, nP), 256, 0, st>>>(Sband, nP, band_nodes);
+  }
   VUS_CHECK_HIP(hipMemsetAsync(counter, 0, sizeof(int), st));
   if (nL > 0) vinv_kernel<<<cdiv(nL, 256), 256, 0, st>>>(nL, lambda, V, Vinv);
-  {
-    constexpr int lds = ST_WAVES * ST_WAVE_DOUBLES * (int)sizeof(double);
-    VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(schur_tiles_kernel<false>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    int n_cu = device_cu_count();
-    if (n_cu < 8) n_cu = 256;
-    int wg = 2 * n_cu;
-    if (wg > T->n_units) wg = T->n_units;
-    if (wg > 0)
-      schur_tiles_kernel<false><<<wg, 64 * ST_WAVES, lds, st>>>(*T, nP, ps, band_nodes, lambda, W, P->obs_ppos, Vinv, Hpp, Sband, counter);
-  }
-  schur_rhs_kernel<<<nP, 64, 0, st>>>(*P, W, Vinv, gl, gp, gs);
-  VUS_CHECK_LAUNCH("ba_schur_tiles");
+  if (nO > 0 && Y != nullptr) ymul_kernel<<<cdiv(nO, 256), 256, 0, st>>>(*P, W, Vinv, Y);   // optional output only
+  constexpr int lds = ST_WAVES * ST_WAVE_DOUBLES * (int)sizeof(double);
+  // (kernel, device) attribute: set per call -- a host-side table write -- instead of once per process
+  VUS_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(schur_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+  int n_cu = device_cu_count();
+  if (n_cu < 8) n_cu = 256;
+  int wg = 2 * n_cu;                 // persistent: two workgroups per CU is what their LDS admits
+  if (wg > T->n_units) wg = T->n_units;
+  schur_tiles_kernel<<<wg, 64 * ST_WAVES, lds, st>>>(*T, nP, ps, band_nodes, lambda, W, Vinv, Hpp, gl, gp, Sband, gs, counter);
+  VUS_CHECK_LAUNCH("ba_schur");
   return VUS_OK;
 }
 
