@@ -340,6 +340,10 @@ def main():
         dt = float(t.item())
 
     stage_ms = timer.stage_ms()
+    fast_parts = None
+    if "fast_threshold" in stage_ms:      # the adaptive detector: threshold estimate (tile sample) + detection + the check
+        fast_parts = {"threshold_estimate": round(stage_ms["fast_threshold"], 4), "detect_and_check": round(stage_ms["fast_detect"], 4)}
+        stage_ms["fast_detect"] += stage_ms.pop("fast_threshold")
     stage_ms = {n: stage_ms[n] for n in STAGES}
     dom = max(stage_ms, key=stage_ms.get)
     n_proc = n_halo                                          # frames this rank's launches really covered
@@ -356,6 +360,7 @@ def main():
                    "parallelism": (f"frames sharded x{world} (+1 halo frame per shard), all_gather of the feature-track "
                                    f"records inside the step" if world > 1 else "1 GPU, no collective")},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+        "fast_detect_parts_ms": fast_parts,
         "pipeline_GBps": round(ALGO_BYTES_FRAME * F * a.steps / dt / 1e9 * world, 2),
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,

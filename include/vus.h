@@ -68,6 +68,32 @@ int vus_fast_detect(const uint8_t* img, int n_img, int H, int W, int pitch, int 
                     uint8_t* blur_out, uint32_t* cand_keys, int cand_cap, int* cand_count,
                     void* stream);
 
+/* ---- the adaptive detector (round 4; the nodelet's fast_threshold, launch/stereo.launch:43, stays the contract) ----
+ * The max_kp best keypoints of an image (vus_select_topk) depend only on pixels whose score reaches s*, the max_kp-th
+ * best score among the non-max-suppression survivors: a pixel below s* can neither be selected nor suppress one at or
+ * above it.  Detection at any per-image threshold thr_img[n] <= s* therefore selects the SAME keypoints as detection at
+ * thr, while far fewer pixels reach the exact score.  Three calls, all asynchronous, no host decision in between:
+ *   vus_fast_threshold_estimate  hist [n_img,256] (scratch, zeroed here): the survivors of a SAMPLE of the 128 x 24-pixel
+ *       tiles (raster order, every sample_stride-th starting at tile sample_stride / 2), detected at thr, counted by
+ *       score; thr_img[n] = the largest t in (thr, 254] with  count(score >= t) * tiles * VUS_FAST_MARGIN_DEN  >=
+ *       max_kp * sampled tiles * VUS_FAST_MARGIN_NUM,  else thr.
+ *   vus_fast_detect_adaptive     vus_fast_detect with the per-image thresholds (device array).
+ *   vus_fast_detect_retry        the check: every image with thr_img[n] > thr and cand_count[n] < max_kp (the estimate
+ *       was too high: s* may lie below thr_img[n]) is detected again at thr -- cand_count[n] reset, candidates
+ *       rewritten; blur_out of the adaptive pass stays valid.  retry_list [n_img] scratch, retry_count[0] = how many.
+ * After the three calls vus_select_topk gives exactly what it gives after vus_fast_detect(thr): bit-identical keys. */
+#define VUS_FAST_MARGIN_NUM 3
+#define VUS_FAST_MARGIN_DEN 2
+#define VUS_FAST_TILE_W 128
+#define VUS_FAST_TILE_H 24
+int vus_fast_threshold_estimate(const uint8_t* img, int n_img, int H, int W, int pitch, int thr, int border, int max_kp,
+                                int sample_stride, int* hist, int* thr_img, void* stream);
+int vus_fast_detect_adaptive(const uint8_t* img, int n_img, int H, int W, int pitch, const int* thr_img, int border,
+                             uint8_t* blur_out, uint32_t* cand_keys, int cand_cap, int* cand_count, void* stream);
+int vus_fast_detect_retry(const uint8_t* img, int n_img, int H, int W, int pitch, int thr, const int* thr_img, int max_kp,
+                          int border, uint32_t* cand_keys, int cand_cap, int* cand_count, int* retry_list, int* retry_count,
+                          void* stream);
+
 /* Keep the max_kp smallest keys of each image, sorted ascending.  kp_keys: [n_img, max_kp]
  * (unused tail = VUS_KEY_INVALID); kp_count[n_img] = min(max_kp, min(cand_count, cand_cap)). */
 int vus_select_topk(const uint32_t* cand_keys, const int* cand_count, int n_img, int cand_cap,

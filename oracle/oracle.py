@@ -96,6 +96,28 @@ def fast_detect(img, thr=10, border=31, cand_cap=32768, want_blur=True, _lib=Non
     return keys, cnt, blur
 
 
+def fast_threshold_estimate(img, thr=10, border=31, max_kp=2000, sample_stride=16):
+    """(hist [n,256], thr_img [n]) of the adaptive detector's sampling step."""
+    img, n, H, W = _img_args(img)
+    hist = np.zeros((n, 256), np.int32); thr_img = np.zeros(n, np.int32)
+    _check(lib().vus_fast_threshold_estimate_cpu(_p(img), n, H, W, W, int(thr), int(border), int(max_kp), int(sample_stride),
+                                                 _p(hist), _p(thr_img)), "fast_threshold_estimate")
+    return hist, thr_img
+
+
+def fast_detect_adaptive(img, thr_img, thr=10, border=31, max_kp=2000, cand_cap=32768):
+    """Adaptive pass + the retry check: (keys, count, retried images)."""
+    img, n, H, W = _img_args(img)
+    thr_img = np.ascontiguousarray(thr_img, np.int32)
+    keys = np.full((n, cand_cap), 0xFFFFFFFF, np.uint32); cnt = np.zeros(n, np.int32)
+    _check(lib().vus_fast_detect_adaptive_cpu(_p(img), n, H, W, W, _p(thr_img), int(border), None, _p(keys), int(cand_cap), _p(cnt)),
+           "fast_detect_adaptive")
+    lst = np.zeros(n, np.int32); m = np.zeros(1, np.int32)
+    _check(lib().vus_fast_detect_retry_cpu(_p(img), n, H, W, W, int(thr), _p(thr_img), int(max_kp), int(border), _p(keys),
+                                           int(cand_cap), _p(cnt), _p(lst), _p(m)), "fast_detect_retry")
+    return keys, cnt, lst[:int(m[0])]
+
+
 def select_topk(cand_keys, cand_count, max_kp, _lib=None):
     cand_keys = np.ascontiguousarray(cand_keys, np.uint32)
     cand_count = np.ascontiguousarray(cand_count, np.int32)

@@ -142,6 +142,67 @@ int vus_fast_detect_cpu(const uint8_t* img, int n_img, int H, int W, int pitch, 
   return VUS_OK;
 }
 
+/* ---- the adaptive detector (include/vus.h): the plain statement of its three calls ---- */
+int vus_fast_threshold_estimate_cpu(const uint8_t* img, int n_img, int H, int W, int pitch, int thr, int border, int max_kp,
+                                    int sample_stride, int* hist, int* thr_img) {
+  if (!img || !hist || !thr_img || thr < 1 || thr > 254 || border < 0 || max_kp < 1 || sample_stride < 1) return VUS_E_INVALID;
+  const int tx = (W + VUS_FAST_TILE_W - 1) / VUS_FAST_TILE_W, ty = (H + VUS_FAST_TILE_H - 1) / VUS_FAST_TILE_H;
+  const long long n_tiles = (long long)tx * ty;
+  long long n_sampled = (n_tiles - sample_stride / 2 + sample_stride - 1) / sample_stride;
+  if (n_sampled < 1) n_sampled = 1;
+  const int cap = H * W;                     /* every pixel could be a candidate */
+  for (int n = 0; n < n_img; ++n) {
+    uint32_t* keys = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap);
+    int cnt = 0;
+    int rc = vus_fast_detect_cpu(img + (size_t)n * H * pitch, 1, H, W, pitch, thr, border, NULL, keys, cap, &cnt);
+    if (rc) { free(keys); return rc; }
+    int* h = hist + 256 * (size_t)n;
+    memset(h, 0, sizeof(int) * 256);
+    for (int i = 0; i < cnt; ++i) {
+      const int pos = (int)(keys[i] & ((1u << VUS_KEY_POS_BITS) - 1u)), sc = 255 - (int)(keys[i] >> VUS_KEY_POS_BITS);
+      const int tile = (pos / W / VUS_FAST_TILE_H) * tx + (pos % W) / VUS_FAST_TILE_W;
+      if (tile >= sample_stride / 2 && (tile - sample_stride / 2) % sample_stride == 0) ++h[sc];
+    }
+    free(keys);
+    long long run = 0;
+    int t = 254;
+    for (; t > thr; --t) {
+      run += h[t];
+      if (run * n_tiles * VUS_FAST_MARGIN_DEN >= (long long)max_kp * n_sampled * VUS_FAST_MARGIN_NUM) break;
+    }
+    thr_img[n] = t;
+  }
+  return VUS_OK;
+}
+
+int vus_fast_detect_adaptive_cpu(const uint8_t* img, int n_img, int H, int W, int pitch, const int* thr_img, int border,
+                                 uint8_t* blur_out, uint32_t* cand_keys, int cand_cap, int* cand_count) {
+  if (!img || !thr_img || !cand_keys || !cand_count) return VUS_E_INVALID;
+  for (int n = 0; n < n_img; ++n) {
+    int rc = vus_fast_detect_cpu(img + (size_t)n * H * pitch, 1, H, W, pitch, thr_img[n], border,
+                                 blur_out ? blur_out + (size_t)n * H * W : NULL, cand_keys + (size_t)n * cand_cap, cand_cap,
+                                 cand_count + n);
+    if (rc) return rc;
+  }
+  return VUS_OK;
+}
+
+int vus_fast_detect_retry_cpu(const uint8_t* img, int n_img, int H, int W, int pitch, int thr, const int* thr_img, int max_kp,
+                              int border, uint32_t* cand_keys, int cand_cap, int* cand_count, int* retry_list,
+                              int* retry_count) {
+  if (!img || !thr_img || !cand_keys || !cand_count || !retry_list || !retry_count) return VUS_E_INVALID;
+  int m = 0;
+  for (int n = 0; n < n_img; ++n)
+    if (thr_img[n] > thr && cand_count[n] < max_kp) {
+      retry_list[m++] = n;
+      int rc = vus_fast_detect_cpu(img + (size_t)n * H * pitch, 1, H, W, pitch, thr, border, NULL,
+                                   cand_keys + (size_t)n * cand_cap, cand_cap, cand_count + n);
+      if (rc) return rc;
+    }
+  retry_count[0] = m;
+  return VUS_OK;
+}
+
 static int cmp_u32(const void* a, const void* b) {
   uint32_t x = *(const uint32_t*)a, y = *(const uint32_t*)b;
   return x < y ? -1 : (x > y ? 1 : 0);

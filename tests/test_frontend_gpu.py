@@ -347,6 +347,85 @@ def test_configs1_launch_shape_1000_frames_matches_oracle_at_both_ends_and_the_m
         assert (sidx >= 0).sum() > 1500 and (tidx >= 0).sum() > 800
 
 
+def _adaptive_images(H, W):
+    """Images that stress the adaptive detector's estimate: textured frames, noise, almost no corners, none at all, and
+    texture confined to one corner of the image (the tile sample sees little of it)."""
+    rng = np.random.default_rng(11)
+    tex = synth.stereo_frames(40, 1, H=H, W=W)[0]                                  # two corner-rich images
+    noise = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    ramp = np.add.outer(np.arange(H), np.arange(W)).astype(np.float64)
+    smooth = (ramp / ramp.max() * 200).astype(np.uint8)
+    few = smooth.copy()
+    for k in range(40):                                                            # 40 bright squares: ~160 corners
+        y, x = int(rng.integers(40, H - 50)), int(rng.integers(40, W - 50))
+        few[y:y + 9, x:x + 9] = 255
+    blank = np.full((H, W), 77, np.uint8)
+    corner = smooth.copy()
+    corner[H - 200:, W - 420:] = tex[0][:200, :420]                                 # all the texture in one corner
+    return np.stack([tex[0], tex[1], noise, few, blank, corner])
+
+
+@pytest.mark.parametrize("shape", [(720, 1280), (360, 642)])
+def test_adaptive_detector_selects_the_same_keypoints_as_fast_threshold(gpu, oracle, shape):
+    """StereoOrbFrontend with the adaptive detector (per-image threshold from a tile sample, verified on the device,
+    failed images detected again at fast_threshold) == the plain detector: keypoints, descriptors and matches bit for bit,
+    whatever the estimate was worth."""
+    from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams
+    H, W = shape
+    K = 2000 if H == 720 else 500
+    imgs = _adaptive_images(H, W)
+    frames = torch.from_numpy(imgs.reshape(3, 2, H, W)).cuda()
+    out = {}
+    for adaptive in (True, False):
+        fe = StereoOrbFrontend(H, W, max_frames=3, params=ImageProcessorParams(max_features=K, adaptive_fast=adaptive,
+                                                                               cand_cap=131072))     # noise: 84 k candidates
+        res = fe.process(frames)
+        torch.cuda.synchronize()
+        out[adaptive] = (fe, {k: getattr(res, k).cpu().numpy().copy() for k in
+                              ("kp_keys", "kp_count", "desc", "angle", "stereo_idx", "stereo_dist", "track_idx", "track_dist")})
+    for k, v in out[True][1].items():
+        assert np.array_equal(v, out[False][1][k]), k
+    fe = out[True][0]
+    thr, retried = fe.fast_thr.cpu().numpy(), fe.fast_retry_list.cpu().numpy()[:int(fe.fast_retry_count.item())]
+    assert (thr[:3] > 40).all()                     # corner-rich images: pruning is really on
+    assert thr[4] == 10 and thr[3] == 10            # too few corners for a threshold above fast_threshold
+    cnt = out[True][1]["kp_count"]
+    assert cnt[4] == 0 and 0 < cnt[3] < K
+    # the oracle's twin of the estimate: same histogram, same thresholds
+    ohist, othr = oracle.fast_threshold_estimate(imgs, 10, 31, K, 16)
+    assert np.array_equal(fe.fast_hist.cpu().numpy(), ohist) and np.array_equal(thr, othr)
+    # what the check must have sent back: images whose adaptive pass cannot yield K candidates
+    okeys, ocnt, oretry = oracle.fast_detect_adaptive(imgs, othr, 10, 31, K, cand_cap=fe.p.cand_cap)
+    assert sorted(retried.tolist()) == sorted(oretry.tolist())
+    kp, kc = oracle.select_topk(okeys, ocnt, K)
+    assert np.array_equal(_u32(fe.kp_keys[:6]), kp) and np.array_equal(cnt, kc)
+
+
+def test_adaptive_detector_check_catches_a_wrong_estimate(gpu, oracle):
+    """vus_fast_detect_retry IS the guarantee: with thresholds far too high for every image (250), all of them fail the
+    count check, are listed and detected again at fast_threshold -- the candidates of vus_fast_detect, exactly."""
+    import visual_underwater_slam_amd._lib as L
+    H, W, K, cap = 360, 640, 800, 32768
+    imgs = _adaptive_images(H, W)[:4]
+    n = len(imgs)
+    d_img = torch.from_numpy(imgs).cuda()
+    thr_img = torch.full((n,), 250, dtype=torch.int32, device="cuda")
+    keys = torch.zeros((n, cap), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros((n,), dtype=torch.int32, device="cuda")
+    lst = torch.zeros((n,), dtype=torch.int32, device="cuda"); m = torch.zeros((1,), dtype=torch.int32, device="cuda")
+    st = L.current_stream_ptr()
+    L.call("vus_fast_detect_adaptive", d_img.data_ptr(), n, H, W, W, thr_img.data_ptr(), 31, None, keys.data_ptr(), cap, cnt.data_ptr(), st)
+    first = cnt.cpu().numpy().copy()
+    L.call("vus_fast_detect_retry", d_img.data_ptr(), n, H, W, W, 10, thr_img.data_ptr(), K, 31, keys.data_ptr(), cap, cnt.data_ptr(),
+           lst.data_ptr(), m.data_ptr(), st)
+    torch.cuda.synchronize()
+    assert (first < K).all() and int(m.item()) == n and sorted(lst.cpu().tolist()) == list(range(n))
+    ekeys, ecnt, _ = oracle.fast_detect(imgs, thr=10, border=31, cand_cap=cap, want_blur=False)
+    assert np.array_equal(cnt.cpu().numpy(), ecnt)
+    for i in range(n):
+        assert np.array_equal(np.sort(_u32(keys[i])[:ecnt[i]]), np.sort(ekeys[i][:ecnt[i]]))
+
+
 def test_track_ids_matches_oracle_and_feeds_get_landmarks(gpu, oracle):
     """vus_track_ids on the GPU == oracle; its features go through vus_triangulate (batch.py:144-176)."""
     from visual_underwater_slam_amd.frontend import StereoOrbFrontend, ImageProcessorParams, triangulate

@@ -14,6 +14,9 @@ SIGNATURES = {
     "vus_fast_score": [_P, c_int, c_int, c_int, c_int, c_int, _P, _P],
     "vus_blur7": [_P, c_int, c_int, c_int, c_int, _P, _P],
     "vus_fast_detect": [_P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P],
+    "vus_fast_threshold_estimate": [_P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
+    "vus_fast_detect_adaptive": [_P, c_int, c_int, c_int, c_int, _P, c_int, _P, _P, c_int, _P, _P],
+    "vus_fast_detect_retry": [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P],
     "vus_select_topk": [_P, _P, c_int, c_int, c_int, _P, _P, _P],
     "vus_orient_rbrief": [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P],
     "vus_hamming_match": [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],

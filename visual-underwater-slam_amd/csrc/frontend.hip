@@ -38,6 +38,7 @@ namespace {
 #endif
 constexpr int TW = VUS_TW;              // output tile width  (1280 = 10 tiles of 128)
 constexpr int TH = VUS_TH;              // output tile height (720 = 30 tiles of 24)
+static_assert(TW == VUS_FAST_TILE_W && TH == VUS_FAST_TILE_H, "the sampling pattern of vus_fast_threshold_estimate is part of the ABI");
 #ifndef VUS_NT
 #define VUS_NT 256
 #endif
@@ -151,12 +152,14 @@ __device__ __forceinline__ bool nms_keep(const uint32_t (&c)[3][3]) {
 #ifndef VUS_FAST_DIAG
 #define VUS_FAST_DIAG 1   // pre-test also on the two diagonal opposite pairs: survivors 33 % -> 25 %, 6.32 -> 6.23 ms
 #endif
-template <bool WRITE_SCORE, bool DETECT, bool BLUR>
-__global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
+// One 128 x 24 tile of image n.  HIST (with DETECT): the non-max-suppression survivors of the tile are not listed but
+// counted by score into hist[256 n + score] (vus_fast_threshold_estimate's sample).
+template <bool WRITE_SCORE, bool DETECT, bool BLUR, bool HIST = false>
+__device__ __forceinline__ void fast_tile_body(
     const uint8_t* __restrict__ img, int H, int W, int pitch, int thr, int border,
     uint8_t* __restrict__ score_out, uint8_t* __restrict__ blur_out,
-    uint32_t* __restrict__ cand_keys, int cand_cap, int* __restrict__ cand_count, int n_img, int tiles_x,
-    int tiles_per_img) {
+    uint32_t* __restrict__ cand_keys, int cand_cap, int* __restrict__ cand_count, int* __restrict__ hist,
+    int n, int tile, int tiles_x) {
   __shared__ uint32_t s_img[IMG_ROWS * IMG_DW];
   __shared__ uint32_t s_score[(WRITE_SCORE || DETECT) ? SC_ROWS * SC_DW : 1];
   __shared__ uint32_t s_h[BLUR ? H_ROWS * H_DW : 2];
@@ -167,12 +170,6 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
   uint32_t* const s_keys = s_img;
 
   const int tid = threadIdx.x;
-  // XCD-aware block -> (image, tile) map: blocks with equal (blockIdx % 8) share an XCD, so all tiles of one
-  // image run on ONE XCD and the halo re-reads of neighbouring tiles hit its L2 instead of HBM (speed only).
-  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const int n = (slot / tiles_per_img) * 8 + xcd;
-  if (n >= n_img) return;
-  const int tile = slot - (slot / tiles_per_img) * tiles_per_img;
   const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
   const uint8_t* im = img + (size_t)n * H * pitch;
 
@@ -373,20 +370,109 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
       for (int e = 0; e < 4; ++e) {
         const int s = byte_of(centre, e);
         if (s > 0 && keep[e] && gx + e >= border && gx + e < W - border) {
-          const int p = atomicAdd(&s_cnt, 1);
-          s_keys[p] = ((uint32_t)(255 - s) << VUS_KEY_POS_BITS) | (uint32_t)(gy * W + gx + e);
+          if (HIST) {
+            atomicAdd(&hist[256 * n + s], 1);       // a sampled tile yields a few dozen survivors: no LDS stage
+          } else {
+            const int p = atomicAdd(&s_cnt, 1);
+            s_keys[p] = ((uint32_t)(255 - s) << VUS_KEY_POS_BITS) | (uint32_t)(gy * W + gx + e);
+          }
         }
       }
     }
-    __syncthreads();
-    const int cnt = s_cnt;
-    if (tid == 0 && cnt > 0) s_base = atomicAdd(&cand_count[n], cnt);
-    __syncthreads();
-    if (cnt > 0) {
-      const int base = s_base;
-      for (int i = tid; i < cnt; i += NTHREADS)
-        if (base + i < cand_cap) cand_keys[(size_t)n * cand_cap + base + i] = s_keys[i];
+    if (!HIST) {
+      __syncthreads();
+      const int cnt = s_cnt;
+      if (tid == 0 && cnt > 0) s_base = atomicAdd(&cand_count[n], cnt);
+      __syncthreads();
+      if (cnt > 0) {
+        const int base = s_base;
+        for (int i = tid; i < cnt; i += NTHREADS)
+          if (base + i < cand_cap) cand_keys[(size_t)n * cand_cap + base + i] = s_keys[i];
+      }
     }
+  }
+}
+
+// XCD-aware block -> (image, tile) map: blocks with equal (blockIdx % 8) share an XCD, so all tiles of one
+// image run on ONE XCD and the halo re-reads of neighbouring tiles hit its L2 instead of HBM (speed only).
+// thr_img (may be null): per-image thresholds of the adaptive detector (vus_fast_detect_adaptive).
+template <bool WRITE_SCORE, bool DETECT, bool BLUR>
+__global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
+    const uint8_t* __restrict__ img, int H, int W, int pitch, int thr, const int* __restrict__ thr_img, int border,
+    uint8_t* __restrict__ score_out, uint8_t* __restrict__ blur_out,
+    uint32_t* __restrict__ cand_keys, int cand_cap, int* __restrict__ cand_count, int n_img, int tiles_x,
+    int tiles_per_img) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n = (slot / tiles_per_img) * 8 + xcd;
+  if (n >= n_img) return;
+  const int tile = slot - (slot / tiles_per_img) * tiles_per_img;
+  fast_tile_body<WRITE_SCORE, DETECT, BLUR>(img, H, W, pitch, thr_img ? thr_img[n] : thr, border, score_out, blur_out, cand_keys,
+                                            cand_cap, cand_count, nullptr, n, tile, tiles_x);
+}
+
+// ---- the adaptive detector (round 4): the top-K keypoints of an image depend only on pixels whose score reaches s*,
+// the K-th best score among the non-max-suppression survivors.  A pixel below s* can neither be selected nor suppress a
+// pixel at or above it (suppression needs a neighbour with a score >= its own).  So detection at ANY threshold
+// t' <= s* gives the same top K as detection at fast_threshold -- and far fewer pixels pass the pre-test of pass 1 and
+// reach the exact score of pass 2, where the kernel's instructions go (configs[1]: s* ~ 128, 25 % of the pixels pass the
+// pre-test at 10, ~5 % at 110).  t' is estimated per image from the survivors' score histogram of a SAMPLE of tiles
+// (every sample_stride-th tile, at fast_threshold), with a margin; whether the estimate was good enough is CHECKED on
+// the device (did the image yield >= K candidates?), and the images that failed are detected again at fast_threshold.
+// Bit-identical keypoints by construction, whatever the estimate.
+__global__ __launch_bounds__(NTHREADS) void fast_sample_kernel(const uint8_t* __restrict__ img, int H, int W, int pitch,
+                                                               int thr, int border, int* __restrict__ hist, int n_img,
+                                                               int tiles_x, int tiles_per_img, int stride, int n_sampled) {
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int n = (slot / n_sampled) * 8 + xcd;
+  if (n >= n_img) return;
+  const int tile = (slot - (slot / n_sampled) * n_sampled) * stride + stride / 2;
+  if (tile >= tiles_per_img) return;
+  fast_tile_body<false, true, false, true>(img, H, W, pitch, thr, border, nullptr, nullptr, nullptr, 0, nullptr, hist, n, tile, tiles_x);
+}
+
+// thr_img[n] = the largest t in [thr, 254] with  (survivors of the sample with score >= t) * n_tiles * den  >=
+// max_kp * n_sampled * num  (num / den: the margin), thr if there is none.  One thread per image.
+__global__ void fast_pick_threshold_kernel(const int* __restrict__ hist, int n_img, int thr, int max_kp, long long n_tiles,
+                                           long long n_sampled, int num, int den, int* __restrict__ thr_img) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= n_img) return;
+  long long run = 0;
+  int t = 254;
+  for (; t > thr; --t) {
+    run += hist[256 * n + t];
+    if (run * n_tiles * den >= (long long)max_kp * n_sampled * num) break;
+  }
+  thr_img[n] = t;
+}
+
+// images whose adaptive pass yielded fewer than max_kp candidates although it ran above fast_threshold: listed,
+// their counts reset (one workgroup)
+__global__ __launch_bounds__(1024) void fast_retry_list_kernel(const int* __restrict__ thr_img, int thr, int max_kp, int n_img,
+                                                               int* __restrict__ cand_count, int* __restrict__ retry_list,
+                                                               int* __restrict__ retry_count) {
+  __shared__ int s_n;
+  if (threadIdx.x == 0) s_n = 0;
+  __syncthreads();
+  for (int n = threadIdx.x; n < n_img; n += 1024)
+    if (thr_img[n] > thr && cand_count[n] < max_kp) {
+      retry_list[atomicAdd(&s_n, 1)] = n;
+      cand_count[n] = 0;
+    }
+  __syncthreads();
+  if (threadIdx.x == 0) retry_count[0] = s_n;
+}
+
+// persistent: (listed image, tile) items at fast_threshold; no work, no cost
+__global__ __launch_bounds__(NTHREADS) void fast_retry_kernel(const uint8_t* __restrict__ img, int H, int W, int pitch, int thr,
+                                                              int border, uint32_t* __restrict__ cand_keys, int cand_cap,
+                                                              int* __restrict__ cand_count, const int* __restrict__ retry_list,
+                                                              const int* __restrict__ retry_count, int tiles_x, int tiles_per_img) {
+  const long long items = (long long)retry_count[0] * tiles_per_img;
+  for (long long it = blockIdx.x; it < items; it += gridDim.x) {
+    const int n = retry_list[it / tiles_per_img], tile = (int)(it % tiles_per_img);
+    fast_tile_body<false, true, false>(img, H, W, pitch, thr, border, nullptr, nullptr, cand_keys, cand_cap, cand_count, nullptr, n,
+                                       tile, tiles_x);
+    __syncthreads();                 // the tile's LDS images are reused by the next item
   }
 }
 
@@ -1508,7 +1594,7 @@ extern "C" int vus_fast_score(const uint8_t* img, int n_img, int H, int W, int p
   if (n_img == 0) return VUS_OK;
   const TileGrid g = tile_grid(n_img, H, W);
   fast_tile_kernel<true, false, false><<<g.blocks, NTHREADS, 0, vus::as_stream(stream)>>>(
-      img, H, W, pitch, thr, 0, score_out, nullptr, nullptr, 0, nullptr, n_img, g.tiles_x, g.tiles_per_img);
+      img, H, W, pitch, thr, nullptr, 0, score_out, nullptr, nullptr, 0, nullptr, n_img, g.tiles_x, g.tiles_per_img);
   VUS_CHECK_LAUNCH("fast_score");
   return VUS_OK;
 }
@@ -1519,7 +1605,7 @@ extern "C" int vus_blur7(const uint8_t* img, int n_img, int H, int W, int pitch,
   if (n_img == 0) return VUS_OK;
   const TileGrid g = tile_grid(n_img, H, W);
   fast_tile_kernel<false, false, true><<<g.blocks, NTHREADS, 0, vus::as_stream(stream)>>>(
-      img, H, W, pitch, 1, 0, nullptr, out, nullptr, 0, nullptr, n_img, g.tiles_x, g.tiles_per_img);
+      img, H, W, pitch, 1, nullptr, 0, nullptr, out, nullptr, 0, nullptr, n_img, g.tiles_x, g.tiles_per_img);
   VUS_CHECK_LAUNCH("blur7");
   return VUS_OK;
 }
@@ -1537,13 +1623,75 @@ extern "C" int vus_fast_detect(const uint8_t* img, int n_img, int H, int W, int 
   const TileGrid g = tile_grid(n_img, H, W);
   if (blur_out)
     fast_tile_kernel<false, true, true><<<g.blocks, NTHREADS, 0, st>>>(
-        img, H, W, pitch, thr, border, nullptr, blur_out, cand_keys, cand_cap, cand_count, n_img, g.tiles_x,
+        img, H, W, pitch, thr, nullptr, border, nullptr, blur_out, cand_keys, cand_cap, cand_count, n_img, g.tiles_x,
         g.tiles_per_img);
   else
     fast_tile_kernel<false, true, false><<<g.blocks, NTHREADS, 0, st>>>(
-        img, H, W, pitch, thr, border, nullptr, nullptr, cand_keys, cand_cap, cand_count, n_img, g.tiles_x,
+        img, H, W, pitch, thr, nullptr, border, nullptr, nullptr, cand_keys, cand_cap, cand_count, n_img, g.tiles_x,
         g.tiles_per_img);
   VUS_CHECK_LAUNCH("fast_detect");
+  return VUS_OK;
+}
+
+extern "C" int vus_fast_threshold_estimate(const uint8_t* img, int n_img, int H, int W, int pitch, int thr, int border,
+                                           int max_kp, int sample_stride, int* hist, int* thr_img, void* stream) {
+  if (int rc = check_image_args(img, n_img, H, W, pitch)) return rc;
+  VUS_REQUIRE(hist != nullptr && thr_img != nullptr, "null buffer");
+  VUS_REQUIRE(thr >= 1 && thr <= 254, "thr=%d out of range [1, 254]", thr);
+  VUS_REQUIRE(border >= 0 && max_kp >= 1 && sample_stride >= 1, "border=%d max_kp=%d sample_stride=%d", border, max_kp, sample_stride);
+  if (n_img == 0) return VUS_OK;
+  hipStream_t st = vus::as_stream(stream);
+  const TileGrid g = tile_grid(n_img, H, W);
+  const int n_sampled = (g.tiles_per_img - sample_stride / 2 + sample_stride - 1) / sample_stride;     // tiles S/2, S/2 + S, ...
+  VUS_CHECK_HIP(hipMemsetAsync(hist, 0, sizeof(int) * 256 * (size_t)n_img, st));
+  if (n_sampled > 0)
+    fast_sample_kernel<<<(unsigned)(((n_img + 7) / 8) * 8 * n_sampled), NTHREADS, 0, st>>>(
+        img, H, W, pitch, thr, border, hist, n_img, g.tiles_x, g.tiles_per_img, sample_stride, n_sampled);
+  fast_pick_threshold_kernel<<<(n_img + 255) / 256, 256, 0, st>>>(hist, n_img, thr, max_kp, g.tiles_per_img, n_sampled > 0 ? n_sampled : 1,
+                                                                 VUS_FAST_MARGIN_NUM, VUS_FAST_MARGIN_DEN, thr_img);
+  VUS_CHECK_LAUNCH("fast_threshold_estimate");
+  return VUS_OK;
+}
+
+extern "C" int vus_fast_detect_adaptive(const uint8_t* img, int n_img, int H, int W, int pitch, const int* thr_img, int border,
+                                        uint8_t* blur_out, uint32_t* cand_keys, int cand_cap, int* cand_count, void* stream) {
+  if (int rc = check_image_args(img, n_img, H, W, pitch)) return rc;
+  VUS_REQUIRE(cand_keys != nullptr && cand_count != nullptr && thr_img != nullptr, "null buffer");
+  VUS_REQUIRE(cand_cap >= 1 && border >= 0, "cand_cap=%d border=%d", cand_cap, border);
+  if (n_img == 0) return VUS_OK;
+  hipStream_t st = vus::as_stream(stream);
+  const TileGrid g = tile_grid(n_img, H, W);
+  if (blur_out)
+    fast_tile_kernel<false, true, true><<<g.blocks, NTHREADS, 0, st>>>(
+        img, H, W, pitch, 0, thr_img, border, nullptr, blur_out, cand_keys, cand_cap, cand_count, n_img, g.tiles_x, g.tiles_per_img);
+  else
+    fast_tile_kernel<false, true, false><<<g.blocks, NTHREADS, 0, st>>>(
+        img, H, W, pitch, 0, thr_img, border, nullptr, nullptr, cand_keys, cand_cap, cand_count, n_img, g.tiles_x, g.tiles_per_img);
+  VUS_CHECK_LAUNCH("fast_detect_adaptive");
+  return VUS_OK;
+}
+
+extern "C" int vus_fast_detect_retry(const uint8_t* img, int n_img, int H, int W, int pitch, int thr, const int* thr_img,
+                                     int max_kp, int border, uint32_t* cand_keys, int cand_cap, int* cand_count,
+                                     int* retry_list, int* retry_count, void* stream) {
+  if (int rc = check_image_args(img, n_img, H, W, pitch)) return rc;
+  VUS_REQUIRE(cand_keys && cand_count && thr_img && retry_list && retry_count, "null buffer");
+  VUS_REQUIRE(thr >= 1 && thr <= 254 && max_kp >= 1 && cand_cap >= 1 && border >= 0, "thr=%d max_kp=%d cand_cap=%d border=%d", thr,
+              max_kp, cand_cap, border);
+  if (n_img == 0) return VUS_OK;
+  hipStream_t st = vus::as_stream(stream);
+  const TileGrid g = tile_grid(n_img, H, W);
+  fast_retry_list_kernel<<<1, 1024, 0, st>>>(thr_img, thr, max_kp, n_img, cand_count, retry_list, retry_count);
+  int n_cu = 256;
+  {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        n_cu < 1)
+      n_cu = 256;
+  }
+  fast_retry_kernel<<<8 * n_cu, NTHREADS, 0, st>>>(img, H, W, pitch, thr, border, cand_keys, cand_cap, cand_count, retry_list,
+                                                   retry_count, g.tiles_x, g.tiles_per_img);
+  VUS_CHECK_LAUNCH("fast_detect_retry");
   return VUS_OK;
 }
 

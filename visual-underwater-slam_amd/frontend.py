@@ -38,6 +38,12 @@ class ImageProcessorParams:
     cross_check: bool = False      # keep a match only if it is mutual (query <-> train swapped gives it back)
     n_levels: int = 1              # ORB scale pyramid: 1 = single level; 8 with scale_factor 1.2 = Rublee et al.
     scale_factor: float = 1.2
+    adaptive_fast: bool = True     # detect at a per-image threshold estimated from a sample of tiles and verified on the
+                                   # device (vus_fast_threshold_estimate / _detect_adaptive / _detect_retry): the SAME
+                                   # max_features keypoints as detection at fast_threshold, bit for bit, at a fraction
+                                   # of the exact-score work.  Applies to the single-level detector with global top-K
+                                   # selection (grid bucketing and the pyramid's per-level quotas need every candidate)
+    fast_sample_stride: int = 16   # every 16th 128 x 24 tile is sampled (6 % of the image)
 
 
 def pyramid_layout(H: int, W: int, max_features: int, n_levels: int, scale_factor: float):
@@ -144,6 +150,12 @@ class StereoOrbFrontend:
         # sticky device-side maximum of the per-image candidate counts since the last check_overflow(): a
         # process(check=False) call that overflowed cand_cap is still reported by the next check
         self.cand_max_seen = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.adaptive = bool(self.p.adaptive_fast and self.p.n_levels == 1 and self.p.grid_max_feature_num <= 0)
+        if self.adaptive:
+            self.fast_hist = torch.zeros((n_img, 256), dtype=torch.int32, device=dev)
+            self.fast_thr = torch.zeros((n_img,), dtype=torch.int32, device=dev)      # the thresholds of the last process()
+            self.fast_retry_list = torch.zeros((n_img,), dtype=torch.int32, device=dev)
+            self.fast_retry_count = torch.zeros((1,), dtype=torch.int32, device=dev)  # images the check sent back to fast_threshold
         if self.p.cross_check:   # backward pairings (same row layout as match_idx)
             self.rev_idx = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
             self.rev_dist = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
@@ -180,8 +192,18 @@ class StereoOrbFrontend:
         mark("begin")
         if self.levels is None:
             self.cand_count[:n_img].zero_()
-            _lib.call("vus_fast_detect", ptr(images), n_img, H, W, W, p.fast_threshold, p.border,
-                      ptr(self.blur), ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
+            if self.adaptive:
+                _lib.call("vus_fast_threshold_estimate", ptr(images), n_img, H, W, W, p.fast_threshold, p.border, K,
+                          p.fast_sample_stride, ptr(self.fast_hist), ptr(self.fast_thr), st)
+                mark("fast_threshold")
+                _lib.call("vus_fast_detect_adaptive", ptr(images), n_img, H, W, W, ptr(self.fast_thr), p.border,
+                          ptr(self.blur), ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
+                _lib.call("vus_fast_detect_retry", ptr(images), n_img, H, W, W, p.fast_threshold, ptr(self.fast_thr), K,
+                          p.border, ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), ptr(self.fast_retry_list),
+                          ptr(self.fast_retry_count), st)
+            else:
+                _lib.call("vus_fast_detect", ptr(images), n_img, H, W, W, p.fast_threshold, p.border,
+                          ptr(self.blur), ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
             mark("fast_detect")
             if p.grid_max_feature_num > 0:
                 _lib.call("vus_select_grid", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, H, W,
