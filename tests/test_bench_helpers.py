@@ -1,12 +1,15 @@
 """Host-side pieces of bench.py / ba_bench.py that can be exercised without a GPU: the JSON objects the driver
 parses must come out well-formed whatever the stage times are."""
 import json
+import os
 import types
 
 import pytest
 
 import bench
 from visual_underwater_slam_amd import ba_bench
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_usable_cores_is_positive_and_bounded_by_affinity():
@@ -63,3 +66,31 @@ def test_bench_command_line_contract_on_a_small_stream(gpu):
     ba = j["ba"]
     assert ba["lm"]["status"] == 0 and ba["value"] > 0 and ba["dropin"]["same_optimum_as_array_path"] is True
     assert ba["roofline"]["bound"] in ("hbm", "mfma")
+
+
+@pytest.mark.gpu
+def test_bench_two_rank_rehearsal_over_gloo_on_the_one_gpu(gpu):
+    """The driver's multi-GPU command line -- torch.distributed.run, one rank per GPU, `bench.py --gpus N` -- rehearsed as
+    two ranks on the ONE visible GPU with VUS_BENCH_BACKEND=gloo (RCCL needs one device per rank): the frame-sharded
+    front-end with its gather, and the landmark-sharded LM with its reduce / broadcast, produce ONE JSON line from rank 0
+    that carries what an 8-GPU result needs to be interpreted (bytes per trial, per-stage times)."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, VUS_BENCH_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--frames", "24", "--ba-sharded-kf", "300"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["value"] > 0 and out["config"]["frames_per_gpu"] == 24
+    sh = out["ba_sharded"]
+    assert sh["lm"]["status"] == 0 and sh["value"] > 0 and sh["config"]["ranks"] == 2
+    assert sh["config"]["reduce_to_rank0_bytes_per_trial"] == 288 * 300 * (sh["config"]["band_blocks"] + 1) + 48 * 300
+    assert set(sh["trial_stage_ms_this_rank"]) == {"linearize+allreduce_err", "schur+reduce_to_rank0", "band_solve_rank0+broadcast_step",
+                                                   "backsub", "eval_step+allreduce_err"}

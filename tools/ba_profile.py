@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from visual_underwater_slam_amd import synth
 from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
-n_kf, n_lm, obs = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else (2000, 50000, 1000)
+n_kf, n_lm, obs = (int(a) for a in sys.argv[1:4]) if len(sys.argv) > 3 else synth.CONFIGS2_BA
 s = synth.ba_sequence(n_kf, n_lm, obs)
 nL = len(s["points_gt"])
 prob = StereoBAProblem(s["obs_pose"], s["obs_point"], s["meas"], n_kf, nL, s["K"], s["sigma"], prior_pose=[0],

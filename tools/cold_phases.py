@@ -7,8 +7,8 @@ import torch
 from visual_underwater_slam_amd import synth, ba_pack, _lib
 from visual_underwater_slam_amd import ba as B
 
-n_kf = 2000
-s = synth.ba_sequence(n_kf, 25 * n_kf, 1000)
+n_kf = synth.CONFIGS2_BA[0]
+s = synth.ba_sequence(*synth.CONFIGS2_BA)
 nL = len(s["points_gt"])
 torch.cuda.init(); torch.zeros(1, device="cuda:0"); torch.cuda.synchronize()
 out = {}

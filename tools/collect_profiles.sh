@@ -1,8 +1,8 @@
 #!/bin/bash
 # Collect the judged profile artefacts on the GPU box (run through gpurun) into gpurun_out/profiles_rNN/.
-# usage: bash tools/collect_profiles.sh r03
+# usage: bash tools/collect_profiles.sh r04
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/profiles_$TAG
 mkdir -p $OUT
@@ -34,8 +34,11 @@ bash $ROOT/tools/pmc_ba.sh $OUT/pmc_ba_${TAG}.txt || true
 /opt/rocm/bin/hipcc -O3 -w --offload-arch=gfx950 $ROOT/tools/ubench/lds_add_f64_rate.hip -o /tmp/lds_add_f64_rate 2>/dev/null && /tmp/lds_add_f64_rate > $OUT/lds_add_f64_rate_${TAG}.txt || true
 # 6. set-up of a configs[2] problem: pack, pair lists (torch sort vs csrc/structure.hip) with the kernel durations
 rm -rf /tmp/prof_st && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_st -- python3 $ROOT/tools/setup_prof.py > $OUT/setup_${TAG}.txt 2>/dev/null || true
-python3 $ROOT/tools/summarize_stats.py /tmp/prof_st 60 | grep -i "structure_rows\|kernel   " >> $OUT/setup_${TAG}.txt || true
-python3 $ROOT/tools/overlap_probe.py 2>/dev/null | tail -2 > $OUT/schur_band_overlap_${TAG}.txt || true
+python3 $ROOT/tools/summarize_stats.py /tmp/prof_st 60 | grep -i "tiles_\|rs_\|kernel   " >> $OUT/setup_${TAG}.txt || true
+# 6b. the landmark elimination alone: one vus_ba_schur call timed with HIP events + kernel stats + PMC (MFMA, LDS, L2, HBM)
+python3 $ROOT/tools/schur_ab.py c2 2>/dev/null | grep '^{' > $OUT/schur_${TAG}.json || true
+python3 $ROOT/tools/schur_ab.py c4 2>/dev/null | grep '^{' >> $OUT/schur_${TAG}.json || true
+bash $ROOT/tools/schur_pmc.sh $OUT/pmc_schur_${TAG}.txt || true
 # 7. round 3: the band solve's panel-step modes A/B in one process (2 = launch pairs on two streams, 3 = persistent window
 #    kernel), and the first optimize() of a process by phase
 python3 $ROOT/tools/band_modes_probe.py 2 3 2>/dev/null | grep '^{' > $OUT/band_modes_${TAG}.txt || true

@@ -3,7 +3,7 @@ import sys, time, numpy as np, torch
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 from visual_underwater_slam_amd import synth
 from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
-s = synth.ba_sequence(2000, 50000, 1000)
+s = synth.ba_sequence(*synth.CONFIGS2_BA)
 nL = len(s["points_gt"])
 prob = StereoBAProblem(s["obs_pose"], s["obs_point"], s["meas"], 2000, nL, s["K"], s["sigma"],
                        prior_pose=[0], prior_T=s["poses_gt"][:1], prior_sigmas=s["prior_sigmas"][None])

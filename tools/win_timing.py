@@ -7,8 +7,8 @@ import torch
 from visual_underwater_slam_amd import synth, _lib, ba_bench
 from visual_underwater_slam_amd.ba import StereoBAProblem, StereoBASolver
 
-n_kf = 2000
-s = synth.ba_sequence(n_kf, 25 * n_kf, 1000)
+n_kf = synth.CONFIGS2_BA[0]
+s = synth.ba_sequence(*synth.CONFIGS2_BA)
 nL = len(s["points_gt"])
 prob = StereoBAProblem(s["obs_pose"], s["obs_point"], s["meas"], n_kf, nL, s["K"], s["sigma"], prior_pose=[0],
                        prior_T=s["poses_gt"][:1], prior_sigmas=s["prior_sigmas"][None])

@@ -431,8 +431,26 @@ def run_sharded(device, world, rank, n_kf=10000, n_lm=500000, obs_per_kf=1000):
     sv.optimize(poses0, points0, LMParams(maxIterations=1))
     poses, pts, rep = sv.optimize(poses0, points0, LMParams())
     band_bytes = 288 * n_kf * (sv.problem.band + 1)
+    # one trial stage by stage on this rank (wall clock, collectives included; every rank makes the same calls): what an
+    # 8-GPU run needs to be read without further instrumentation -- which stage the exchange sits in and what it costs
+    inner, pl = sv.solver, points0[sv.lo:sv.hi].contiguous()
+    stage = {}
+
+    def timed(name, fn):
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        stage.setdefault(name, []).append(1e3 * (time.perf_counter() - t))
+    for _ in range(3):
+        timed("linearize+allreduce_err", lambda: inner.linearize(poses0, pl))
+        timed("schur+reduce_to_rank0", lambda: inner.schur(1e-5))
+        timed("band_solve_rank0+broadcast_step", lambda: inner.band_solve())
+        timed("backsub", lambda: inner.backsub())
+        timed("eval_step+allreduce_err", lambda: inner.eval_step(poses0, pl))
     return {
         "seconds": rep.seconds, "data_generation_s": round(gen_s, 2),
+        "trial_stage_ms_this_rank": {k: round(statistics.median(v), 3) for k, v in stage.items()},
         "config": {"workload": "configs[4]: landmark block-row partitioned Schur BA", "keyframes": n_kf, "landmarks": nL,
                    "stereo_factors": len(s["obs_pose"]), "band_blocks": sv.problem.band, "ranks": world,
                    "local_landmarks": sv.hi - sv.lo, "local_stereo_factors": sv.problem.n_obs,
