@@ -368,6 +368,22 @@ def main():
                      "note": "HBM reading of a kernel that is VALU-issue bound (see `valu`): traffic = FETCH_SIZE+WRITE_SIZE of "
                              "a separate rocprofv3 --pmc run (profiles/traffic.json), scaled to this launch"},
     }
+    # every stage with its two readings: algorithmic bytes over the stage time against HBM, and -- where the committed PMC
+    # summary has SQ_INSTS_VALU for its kernel -- vector wave-instructions over the stage time against the VALU issue peak
+    # (1.04 ns per wave-instruction per SIMD).  orient_rbrief: one wave per keypoint, ~230 vector instructions each; what
+    # it waits for is its own LDS round trips and the patch gather, neither HBM nor issue.
+    rs = {}
+    for name in STAGES:
+        b = ALGO_BYTES[name] * n_proc
+        t_ms = stage_ms[name]
+        tr, vi, _ = measured_counters(name, n_proc)
+        e = {"bound": "hbm", "algorithmic_bytes_per_launch": b, "achieved": round(b / (t_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": round(b / (t_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": tr, "ms": round(t_ms, 4)}
+        if vi:
+            e["valu_wave_insts_per_launch"] = int(vi)
+            e["valu_issue_frac"] = round(vi * 1.04e-9 / N_SIMD / (t_ms * 1e-3), 3)
+        rs[name] = e
+    out["roofline_stages"] = rs
     if valu_insts and valu_ns:
         # The roof that binds: vector-ALU instruction issue.  SQ_INSTS_VALU of the launch spread over the chip's SIMDs
         # at (a) the full issue rate (v_add/v_xor class, 1.04 ns per wave-instruction per SIMD, measured by
