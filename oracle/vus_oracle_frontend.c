@@ -15,7 +15,11 @@
  *     smoothed 31x31 patch: Rublee et al., "ORB", ICCV 2011, sec. 3.2 and 4.2.
  *   - brute-force Hamming matching with a row gate (stereo_threshold=5 = stereo.launch:47).
  *   - get_landmarks: batch.py:144-176 (this one IS in the reference and is followed verbatim).
- * The oracle is pinned only by the known-answer tests in tests/ (hand-built patches), by
+ * PINNED BY THE REFERENCE ITSELF (round 4): vus_triangulate_cpu and vus_emit_stereo_factors_cpu -- get_landmarks and the
+ * landmark loop of batch_create, batch.py:144-176, 295-305 -- are checked against outputs of /root/reference/batch.py,
+ * run unmodified in the build container (tests/golden/make_reference_fixtures.py -> tests/golden/ref_batch_*.npz;
+ * tests/test_reference_fixtures.py): measurements and factor order bit for bit, world points to 1 ulp.
+ * For FAST / orientation / rBRIEF / Hamming the oracle is pinned only by the known-answer tests in tests/ (hand-built patches), by
  * self-generated golden vectors under tests/golden/, and -- detector corner set and orientation bin
  * only -- by agreement with scikit-image 0.18.3, an independent implementation of the same published
  * algorithms (tests/test_thirdparty_crosscheck.py).

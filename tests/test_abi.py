@@ -44,6 +44,8 @@ def test_build_target_is_reported_and_checked_against_the_device_name():
     assert L.target_mismatch("gfx950", "gfx950:sramecc+:xnack+") is None               # a generic object runs anywhere
     assert "OFFLOAD=--offload-arch=gfx950" in L.target_mismatch("gfx950:xnack-", "gfx950:sramecc+:xnack+")
     assert "gfx942" in L.target_mismatch("gfx950:xnack-", "gfx942:sramecc+:xnack-")
+    # the device is only asked for its target ID when a launch has failed for want of a code object
+    assert L._explain_missing_code_object("null buffer") == "null buffer"
 
 
 def test_oracle_exports_cpu_twins(oracle):

@@ -109,7 +109,7 @@ def call(name, *args):
     lib = load()
     rc = getattr(lib, name)(*args)
     if rc != 0:
-        raise VusError(f"{name} failed ({rc}): {lib.vus_last_error().decode()}")
+        raise VusError(f"{name} failed ({rc}): {_explain_missing_code_object(lib.vus_last_error().decode())}")
 
 
 def ptr(t):
@@ -138,18 +138,33 @@ def target_mismatch(built: str, device_arch: str):
     return None
 
 
-_target_checked = False
+def _explain_missing_code_object(text: str) -> str:
+    """A launch that fails because no code object of the library matches the device says "no kernel image is available" /
+    "invalid device function" and nothing else.  Only THEN is the device's target ID looked up (hipGetDeviceProperties
+    costs ~30 ms the first time in a process: measured as 42 -> 75 ms on the first optimize() of a process when it sat in
+    require_gpu()) and compared with the one the library was built for."""
+    if "no kernel image" not in text and "invalid device function" not in text:
+        return text
+    try:
+        import torch
+        arch = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")
+        why = target_mismatch(load().vus_build_target().decode(), arch) if arch else None
+    except Exception:
+        why = None
+    return f"{text} -- {why}" if why else text
+
+
+def check_target():
+    """Explicit form of the same check (diagnostics, tests): raises if the library's code objects cannot load here."""
+    import torch
+    arch = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")
+    why = target_mismatch(load().vus_build_target().decode(), arch) if arch else None
+    if why:
+        raise RuntimeError(why)
 
 
 def require_gpu():
-    global _target_checked
     import torch
     if not torch.cuda.is_available():
         raise RuntimeError("visual_underwater_slam_amd needs an MI355X (HIP device); no GPU is visible "
                            "and there is deliberately no CPU fallback.")
-    if not _target_checked:
-        arch = getattr(torch.cuda.get_device_properties(torch.cuda.current_device()), "gcnArchName", "")
-        why = target_mismatch(load().vus_build_target().decode(), arch) if arch else None
-        if why:
-            raise RuntimeError(why)
-        _target_checked = True
