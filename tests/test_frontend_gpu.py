@@ -392,7 +392,7 @@ def test_adaptive_detector_selects_the_same_keypoints_as_fast_threshold(gpu, ora
     cnt = out[True][1]["kp_count"]
     assert cnt[4] == 0 and 0 < cnt[3] < K
     # the oracle's twin of the estimate: same histogram, same thresholds
-    ohist, othr = oracle.fast_threshold_estimate(imgs, 10, 31, K, 16)
+    ohist, othr = oracle.fast_threshold_estimate(imgs, 10, 31, K, fe.p.fast_sample_stride)
     assert np.array_equal(fe.fast_hist.cpu().numpy(), ohist) and np.array_equal(thr, othr)
     # what the check must have sent back: images whose adaptive pass cannot yield K candidates
     okeys, ocnt, oretry = oracle.fast_detect_adaptive(imgs, othr, 10, 31, K, cand_cap=fe.p.cand_cap)

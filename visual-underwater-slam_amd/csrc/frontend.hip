@@ -355,27 +355,30 @@ __device__ __forceinline__ void fast_tile_body(
     }
   }
   if (DETECT) {
-    for (int idx = tid; idx < TH * STRIPS; idx += NTHREADS) {
-      const int ly = idx / STRIPS, ls = idx - ly * STRIPS;
-      const int gy = y0 + ly, gx = x0 + 4 * ls;
-      const uint32_t centre = s_score[(ly + 1) * SC_DW + ls + 1];
-      if (centre == 0u || gy < border || gy >= H - border) continue;
-      uint32_t c[3][3];
-#pragma unroll
-      for (int k = 0; k < 3; ++k)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) c[k][j] = s_score[(ly + k) * SC_DW + ls + j];
-      const bool keep[4] = {nms_keep<0>(c), nms_keep<1>(c), nms_keep<2>(c), nms_keep<3>(c)};
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int s = byte_of(centre, e);
-        if (s > 0 && keep[e] && gx + e >= border && gx + e < W - border) {
-          if (HIST) {
-            atomicAdd(&hist[256 * n + s], 1);       // a sampled tile yields a few dozen survivors: no LDS stage
-          } else {
-            const int p = atomicAdd(&s_cnt, 1);
-            s_keys[p] = ((uint32_t)(255 - s) << VUS_KEY_POS_BITS) | (uint32_t)(gy * W + gx + e);
-          }
+    // Non-max suppression over the SURVIVOR LIST of pass 2, not over the tile (round 4): with the adaptive threshold a
+    // tile keeps a few hundred scored pixels of 3536, yet nearly every 4-pixel strip of a wave's 64 had one in it, so the
+    // strip loop ran its 3 x 3-dword windows for the whole tile (~700 of the tile's ~4600 wave-instructions).  A list
+    // entry is the pixel's byte index in the score tile: its eight neighbours are eight byte reads.
+    const int nwork = s_nwork;
+    const uint8_t* score8 = reinterpret_cast<const uint8_t*>(s_score);
+    for (int j = tid; j < nwork; j += NTHREADS) {
+      const int ent = s_work[j];
+      const int s = score8[ent];
+      if (s == 0) continue;
+      const int sr = ent / (4 * SC_DW), sx = ent - sr * (4 * SC_DW);     // row / byte column inside the score tile
+      const int ly = sr - 1, lx = sx - 4;                                 // the ring belongs to the neighbouring tiles
+      if (ly < 0 || ly >= TH || lx < 0 || lx >= TW) continue;
+      const int gy = y0 + ly, gx = x0 + lx;
+      if (gy < border || gy >= H - border || gx < border || gx >= W - border) continue;
+      const uint8_t* c = score8 + ent;
+      constexpr int RB = 4 * SC_DW;
+      const int m = max(max3i(c[-RB - 1], c[-RB], c[-RB + 1]), max(max(c[-1], c[1]), max3i(c[RB - 1], c[RB], c[RB + 1])));
+      if (s > m) {                                                         // strict maximum of its 8 neighbours
+        if (HIST) {
+          atomicAdd(&hist[256 * n + s], 1);       // a sampled tile yields a few dozen survivors: no LDS stage
+        } else {
+          const int p = atomicAdd(&s_cnt, 1);
+          s_keys[p] = ((uint32_t)(255 - s) << VUS_KEY_POS_BITS) | (uint32_t)(gy * W + gx);
         }
       }
     }

@@ -43,7 +43,8 @@ class ImageProcessorParams:
                                    # max_features keypoints as detection at fast_threshold, bit for bit, at a fraction
                                    # of the exact-score work.  Applies to the single-level detector with global top-K
                                    # selection (grid bucketing and the pyramid's per-level quotas need every candidate)
-    fast_sample_stride: int = 16   # every 16th 128 x 24 tile is sampled (6 % of the image)
+    fast_sample_stride: int = 32   # every 32nd 128 x 24 tile is sampled (3 % of the image: ~90 survivors decide, 3.9 sigma
+                                   # from a wrong answer at the 1.5x margin -- and a wrong answer only costs that image a retry)
 
 
 def pyramid_layout(H: int, W: int, max_features: int, n_levels: int, scale_factor: float):
