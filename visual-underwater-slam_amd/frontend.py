@@ -41,8 +41,8 @@ class ImageProcessorParams:
     adaptive_fast: bool = True     # detect at a per-image threshold estimated from a sample of tiles and verified on the
                                    # device (vus_fast_threshold_estimate / _detect_adaptive / _detect_retry): the SAME
                                    # max_features keypoints as detection at fast_threshold, bit for bit, at a fraction
-                                   # of the exact-score work.  Applies to the single-level detector with global top-K
-                                   # selection (grid bucketing and the pyramid's per-level quotas need every candidate)
+                                   # of the exact-score work.  Applies wherever a global top-K follows (single level, or
+                                   # every pyramid level with its quota); grid bucketing needs every candidate: off there
     fast_sample_stride: int = 32   # every 32nd 128 x 24 tile is sampled (3 % of the image: ~90 survivors decide, 3.9 sigma
                                    # from a wrong answer at the 1.5x margin -- and a wrong answer only costs that image a retry)
 
@@ -151,7 +151,8 @@ class StereoOrbFrontend:
         # sticky device-side maximum of the per-image candidate counts since the last check_overflow(): a
         # process(check=False) call that overflowed cand_cap is still reported by the next check
         self.cand_max_seen = torch.zeros((1,), dtype=torch.int32, device=dev)
-        self.adaptive = bool(self.p.adaptive_fast and self.p.n_levels == 1 and self.p.grid_max_feature_num <= 0)
+        # per pyramid level the top-K is the level's quota: the same argument holds level by level
+        self.adaptive = bool(self.p.adaptive_fast and self.p.grid_max_feature_num <= 0)
         if self.adaptive:
             self.fast_hist = torch.zeros((n_img, 256), dtype=torch.int32, device=dev)
             self.fast_thr = torch.zeros((n_img,), dtype=torch.int32, device=dev)      # the thresholds of the last process()
@@ -262,8 +263,17 @@ class StereoOrbFrontend:
                 _lib.call("vus_resize_bilinear", ptr(prev), n_img, P["H"], P["W"], P["W"], ptr(L["img"]), h, w, w, st)
                 prev = L["img"]
             self.cand_count[:n_img].zero_()
-            _lib.call("vus_fast_detect", ptr(prev), n_img, h, w, w, p.fast_threshold, p.border, ptr(L["blur"]),
-                      ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
+            if self.adaptive:
+                _lib.call("vus_fast_threshold_estimate", ptr(prev), n_img, h, w, w, p.fast_threshold, p.border, L["quota"],
+                          p.fast_sample_stride, ptr(self.fast_hist), ptr(self.fast_thr), st)
+                _lib.call("vus_fast_detect_adaptive", ptr(prev), n_img, h, w, w, ptr(self.fast_thr), p.border, ptr(L["blur"]),
+                          ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
+                _lib.call("vus_fast_detect_retry", ptr(prev), n_img, h, w, w, p.fast_threshold, ptr(self.fast_thr), L["quota"],
+                          p.border, ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), ptr(self.fast_retry_list),
+                          ptr(self.fast_retry_count), st)
+            else:
+                _lib.call("vus_fast_detect", ptr(prev), n_img, h, w, w, p.fast_threshold, p.border, ptr(L["blur"]),
+                          ptr(self.cand_keys), p.cand_cap, ptr(self.cand_count), st)
             torch.maximum(self.pyr_cand_max, self.cand_count[:n_img].max().reshape(1), out=self.pyr_cand_max)
             _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, L["quota"],
                       ptr(L["keys"]), ptr(L["count"]), st)
