@@ -38,7 +38,12 @@ namespace {
 #endif
 constexpr int TW = VUS_TW;              // output tile width  (1280 = 10 tiles of 128)
 constexpr int TH = VUS_TH;              // output tile height (720 = 30 tiles of 24)
+#ifndef VUS_AB_TILE   // tools/ab experiments only
 static_assert(TW == VUS_FAST_TILE_W && TH == VUS_FAST_TILE_H, "the sampling pattern of vus_fast_threshold_estimate is part of the ABI");
+#endif
+#ifndef VUS_FAST_WPE
+#define VUS_FAST_WPE 1    // second __launch_bounds__ argument of the tile kernels: waves per SIMD the compiler must allow
+#endif
 #ifndef VUS_NT
 #define VUS_NT 256
 #endif
@@ -149,6 +154,9 @@ __device__ __forceinline__ bool nms_keep(const uint32_t (&c)[3][3]) {
   return s > m;
 }
 
+#ifndef VUS_FAST_STRIP
+#define VUS_FAST_STRIP 1  // strip-level pre-test from per-dword extrema before the per-pixel one (see pass 1a)
+#endif
 #ifndef VUS_FAST_DIAG
 #define VUS_FAST_DIAG 1   // pre-test also on the two diagonal opposite pairs: survivors 33 % -> 25 %, 6.32 -> 6.23 ms
 #endif
@@ -162,8 +170,16 @@ __device__ __forceinline__ void fast_tile_body(
     int n, int tile, int tiles_x) {
   __shared__ uint32_t s_img[IMG_ROWS * IMG_DW];
   __shared__ uint32_t s_score[(WRITE_SCORE || DETECT) ? SC_ROWS * SC_DW : 1];
-  __shared__ uint32_t s_h[BLUR ? H_ROWS * H_DW : 2];
+  // the strip pre-test's tables (s_mm, s_strip) live in the horizontal-blur buffer, which is not written before pass 2
+  constexpr bool STRIP = VUS_FAST_STRIP && (WRITE_SCORE || DETECT);
+  constexpr int AUX_DW = STRIP ? (IMG_ROWS * IMG_DW + SC_ROWS * SC_DW + 1) / 2 : 2;
+  __shared__ uint32_t s_h[(BLUR && H_ROWS * H_DW > AUX_DW) ? H_ROWS * H_DW : AUX_DW];
   __shared__ uint16_t s_work[(WRITE_SCORE || DETECT) ? SC_ROWS * SC_DW * 4 : 2];   // pixels that pass the pre-test
+#if VUS_FAST_STRIP
+  uint16_t* const s_mm = reinterpret_cast<uint16_t*>(s_h);       // min | max << 8 of each staged dword
+  uint16_t* const s_strip = s_mm + IMG_ROWS * IMG_DW;            // strips that pass the strip test
+  __shared__ int s_nstrip;
+#endif
   __shared__ int s_cnt, s_base, s_nwork;
   // the candidate list reuses the image tile, which is dead after the second barrier
   static_assert(IMG_ROWS * IMG_DW >= TW * TH / 4, "candidate list must fit in the image tile");
@@ -184,20 +200,45 @@ __device__ __forceinline__ void fast_tile_body(
     const int c0 = clampi(gx, 0, W - 1), c1 = clampi(gx + 1, 0, W - 1), c2 = clampi(gx + 2, 0, W - 1),
               c3 = clampi(gx + 3, 0, W - 1);
     if (r0 < RPP) {
+      // all loads of the thread are issued before the first is used (round 4: the per-row "load, wait, write" chain was
+      // five global-memory latencies long); rows past the tile load a valid row again and are not written
+      constexpr int NP = (IMG_ROWS + RPP - 1) / RPP;
+      uint32_t v[NP];
+      const uint8_t* rp[NP];
 #pragma unroll
-      for (int k = 0; k < (IMG_ROWS + RPP - 1) / RPP; ++k) {
+      for (int k = 0; k < NP; ++k) rp[k] = im + (size_t)clampi(y0 - 4 + min(r0 + RPP * k, IMG_ROWS - 1), 0, H - 1) * pitch;
+      if (fast) {
+#pragma unroll
+        for (int k = 0; k < NP; ++k) __builtin_memcpy(&v[k], rp[k] + gx, 4);
+      } else {
+        uint8_t q[NP][4];
+#pragma unroll
+        for (int k = 0; k < NP; ++k) { q[k][0] = rp[k][c0]; q[k][1] = rp[k][c1]; q[k][2] = rp[k][c2]; q[k][3] = rp[k][c3]; }
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+          v[k] = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 8) | ((uint32_t)q[k][2] << 16) | ((uint32_t)q[k][3] << 24);
+      }
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
         const int row = r0 + RPP * k;
         if (row < IMG_ROWS) {
-          const uint8_t* rp = im + (size_t)clampi(y0 - 4 + row, 0, H - 1) * pitch;
-          uint32_t v;
-          if (fast) __builtin_memcpy(&v, rp + gx, 4);
-          else v = (uint32_t)rp[c0] | ((uint32_t)rp[c1] << 8) | ((uint32_t)rp[c2] << 16) | ((uint32_t)rp[c3] << 24);
-          s_img[row * IMG_DW + col] = v;
+          s_img[row * IMG_DW + col] = v[k];
+#if VUS_FAST_STRIP
+          if (WRITE_SCORE || DETECT) {
+            const int b0 = byte_of(v[k], 0), b1 = byte_of(v[k], 1), b2 = byte_of(v[k], 2), b3 = byte_of(v[k], 3);
+            s_mm[row * IMG_DW + col] = (uint16_t)(min(min(b0, b1), min(b2, b3)) | (max(max(b0, b1), max(b2, b3)) << 8));
+          }
+#endif
         }
       }
     }
   }
-  if (tid == 0) { s_cnt = 0; s_nwork = 0; }
+  if (tid == 0) {
+    s_cnt = 0; s_nwork = 0;
+#if VUS_FAST_STRIP
+    s_nstrip = 0;
+#endif
+  }
   __syncthreads();
 
   if (WRITE_SCORE || DETECT) {
@@ -206,6 +247,67 @@ __device__ __forceinline__ void fast_tile_body(
     // contains one pixel of every opposite pair, so a corner needs  min over the tested pairs of max(pair) > p + thr
     // or  max over the pairs of min(pair) < p - thr  (pairs tested: N/S, E/W and the two diagonals).  Survivors are compacted into an LDS work list (wave prefix
     // sum with DPP, one LDS atomic per wave) so that pass 2 runs the full score on dense lanes.
+#if VUS_FAST_STRIP
+    // Pass 1a (round 4) -- an even cheaper necessary test per STRIP, from the per-dword extrema recorded while staging:
+    // a pixel of the strip can pass the N/S + E/W pair test only if
+    //    max(max N dword, max S dword) > min(strip) + thr  and  max(max W dword, max E dword, b0, b3) > min(strip) + thr
+    // (its N/S neighbours are bytes of the dwords above / below, its W/E neighbours lie in the dword to the left plus
+    // the strip's first byte / the strip's last byte plus the dword to the right), or the mirrored condition on the
+    // dark side.  Measured on the configs[1] frames: 9.0 % of the strips pass at the adaptive threshold where 8.2 % hold
+    // a pixel that passes the per-pixel test, 47 % against 45 % at fast_threshold 10.  The per-pixel test then runs on
+    // the listed strips only.
+    // all iterations are evaluated first and listed with ONE LDS atomic per wave
+    constexpr int NIT = (SC_ROWS * SC_DW + NTHREADS - 1) / NTHREADS;
+    unsigned long long bal[NIT];
+    bool pass[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int idx = it * NTHREADS + tid;
+      pass[it] = false;
+      if (idx < SC_ROWS * SC_DW) {
+        const int sr = idx / SC_DW, ss = idx - sr * SC_DW;
+        const int gy = y0 - 1 + sr, gx = x0 - 4 + 4 * ss;
+        if (gy >= 3 && gy < H - 3 && gx + 3 >= 3 && gx < W - 3) {
+          const int ci = (sr + 3) * IMG_DW + ss;
+          const int ma = s_mm[ci], mb = s_mm[ci + 1], mc = s_mm[ci + 2];
+          const int mn = s_mm[sr * IMG_DW + ss + 1], ms = s_mm[(sr + 6) * IMG_DW + ss + 1];
+          const uint32_t b = s_img[ci + 1];
+          const int b0 = byte_of(b, 0), b3 = byte_of(b, 3);
+          const int pmin = mb & 0xFF, pmax = mb >> 8;
+          const int hi = min(max(mn >> 8, ms >> 8), max3i(ma >> 8, mc >> 8, max(b0, b3)));
+          const int lo = max(min(mn & 0xFF, ms & 0xFF), min3i(ma & 0xFF, mc & 0xFF, min(b0, b3)));
+          pass[it] = hi > pmin + thr || lo < pmax - thr;
+        }
+        s_score[idx] = 0u;
+      }
+      bal[it] = __ballot(pass[it]);
+    }
+    int total = 0;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) total += __popcll(bal[it]);
+    if (total > 0) {
+      int base = 0;
+      if ((tid & 63) == 0) base = atomicAdd(&s_nstrip, total);
+      base = __builtin_amdgcn_readfirstlane(base);
+#pragma unroll
+      for (int it = 0; it < NIT; ++it) {
+        if (pass[it])
+          s_strip[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[it] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[it], 0))] =
+              (uint16_t)(it * NTHREADS + tid);
+        base += __popcll(bal[it]);
+      }
+    }
+    __syncthreads();
+    const int nstrip = s_nstrip;
+    for (int j0 = 0; j0 < nstrip; j0 += NTHREADS) {   // uniform trip count (wave scans inside)
+      const int j = j0 + tid;
+      int mask = 0, idx = 0;
+      if (j < nstrip) {
+        idx = s_strip[j];
+        const int sr = idx / SC_DW, ss = idx - sr * SC_DW;
+        const int gx = x0 - 4 + 4 * ss;
+        {
+#else
     for (int idx0 = 0; idx0 < SC_ROWS * SC_DW; idx0 += NTHREADS) {   // uniform trip count (wave scans inside)
       const int idx = idx0 + tid;
       int mask = 0;
@@ -213,6 +315,7 @@ __device__ __forceinline__ void fast_tile_body(
         const int sr = idx / SC_DW, ss = idx - sr * SC_DW;
         const int gy = y0 - 1 + sr, gx = x0 - 4 + 4 * ss;
         if (gy >= 3 && gy < H - 3 && gx + 3 >= 3 && gx < W - 3) {
+#endif
           const uint32_t* cp = &s_img[(sr + 3) * IMG_DW + ss];
           const uint32_t a = cp[0], b = cp[1], c = cp[2];
           const uint32_t nn = s_img[sr * IMG_DW + ss + 1], so = s_img[(sr + 6) * IMG_DW + ss + 1];
@@ -243,7 +346,9 @@ __device__ __forceinline__ void fast_tile_body(
               if (gx + e < 3 || gx + e >= W - 3) mask &= ~(1 << e);
           }
         }
+#if !VUS_FAST_STRIP
         s_score[idx] = 0u;
+#endif
       }
       const int cnt = __popc(mask);
       int incl = cnt;   // inclusive wave scan (same DPP sequence as wave_sum_i32)
@@ -263,7 +368,7 @@ __device__ __forceinline__ void fast_tile_body(
         if (mask & (1 << e)) s_work[pos++] = (uint16_t)(idx * 4 + e);
     }
   }
-  if (BLUR) {
+  auto blur_rows = [&]() {
     // horizontal 7-tap pass: 4 outputs per item from 3 dwords, two v_dot4_u32_u8 per output
     constexpr uint32_t W0123 = 18u | (33u << 8) | (49u << 16) | (56u << 24);
     constexpr uint32_t W456 = 49u | (33u << 8) | (18u << 16);
@@ -282,9 +387,11 @@ __device__ __forceinline__ void fast_tile_body(
       uint2 out = make_uint2(o0 | (o1 << 16), o2 | (o3 << 16));
       *reinterpret_cast<uint2*>(&s_h[hr * H_DW + 2 * hs]) = out;
     }
-  }
+  };
+  if (BLUR && !STRIP) blur_rows();
   __syncthreads();
 
+  if (BLUR && STRIP) blur_rows();   // after the barrier: its buffer held the strip tables until here
   if (WRITE_SCORE || DETECT) {
     // Pass 2 -- exact FAST score of the survivors, one pixel per lane.  The 12-byte row windows are
     // re-aligned with v_alignbyte so that the pixel sits at byte 4 and the strip code (E = 0) applies.
@@ -400,7 +507,7 @@ __device__ __forceinline__ void fast_tile_body(
 // image run on ONE XCD and the halo re-reads of neighbouring tiles hit its L2 instead of HBM (speed only).
 // thr_img (may be null): per-image thresholds of the adaptive detector (vus_fast_detect_adaptive).
 template <bool WRITE_SCORE, bool DETECT, bool BLUR>
-__global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
+__global__ __launch_bounds__(NTHREADS, VUS_FAST_WPE) void fast_tile_kernel(
     const uint8_t* __restrict__ img, int H, int W, int pitch, int thr, const int* __restrict__ thr_img, int border,
     uint8_t* __restrict__ score_out, uint8_t* __restrict__ blur_out,
     uint32_t* __restrict__ cand_keys, int cand_cap, int* __restrict__ cand_count, int n_img, int tiles_x,
@@ -422,7 +529,7 @@ __global__ __launch_bounds__(NTHREADS) void fast_tile_kernel(
 // (every sample_stride-th tile, at fast_threshold), with a margin; whether the estimate was good enough is CHECKED on
 // the device (did the image yield >= K candidates?), and the images that failed are detected again at fast_threshold.
 // Bit-identical keypoints by construction, whatever the estimate.
-__global__ __launch_bounds__(NTHREADS) void fast_sample_kernel(const uint8_t* __restrict__ img, int H, int W, int pitch,
+__global__ __launch_bounds__(NTHREADS, VUS_FAST_WPE) void fast_sample_kernel(const uint8_t* __restrict__ img, int H, int W, int pitch,
                                                                int thr, int border, int* __restrict__ hist, int n_img,
                                                                int tiles_x, int tiles_per_img, int stride, int n_sampled) {
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
@@ -466,7 +573,7 @@ __global__ __launch_bounds__(1024) void fast_retry_list_kernel(const int* __rest
 }
 
 // persistent: (listed image, tile) items at fast_threshold; no work, no cost
-__global__ __launch_bounds__(NTHREADS) void fast_retry_kernel(const uint8_t* __restrict__ img, int H, int W, int pitch, int thr,
+__global__ __launch_bounds__(NTHREADS, VUS_FAST_WPE) void fast_retry_kernel(const uint8_t* __restrict__ img, int H, int W, int pitch, int thr,
                                                               int border, uint32_t* __restrict__ cand_keys, int cand_cap,
                                                               int* __restrict__ cand_count, const int* __restrict__ retry_list,
                                                               const int* __restrict__ retry_count, int tiles_x, int tiles_per_img) {
