@@ -157,9 +157,102 @@ __device__ __forceinline__ bool nms_keep(const uint32_t (&c)[3][3]) {
 #ifndef VUS_FAST_STRIP
 #define VUS_FAST_STRIP 1  // strip-level pre-test from per-dword extrema before the per-pixel one (see pass 1a)
 #endif
+#ifndef VUS_BLUR_MFMA
+#define VUS_BLUR_MFMA 1   // the 7x7 smoothing as two banded int8 GEMMs on the matrix cores (see blur_tile_mfma)
+#endif
 #ifndef VUS_FAST_DIAG
 #define VUS_FAST_DIAG 1   // pre-test also on the two diagonal opposite pairs: survivors 33 % -> 25 %, 6.32 -> 6.23 ms
 #endif
+// ---- the 7 x 7 smoothing of a staged tile on the matrix cores (round 4).  Both passes of the separable filter are
+// products with a banded (Toeplitz) weight matrix, and v_mfma_i32_16x16x32_i8 computes a 16 x 16 block of such a
+// product over a K window of 32 -- the 22 inputs a 16-wide block needs fit.  Exact integer arithmetic, same result as
+// the VALU form (u16 row sums, then sum w H + 32768 >> 16):
+//   H pass   C[row][col] = sum_k img[row][k] T[k][col]      A = 8 consecutive image bytes of a row (one ds_read_b64),
+//            B = the weights, a per-lane constant.  The bytes are unsigned and the instruction is signed: a ^ 0x80 =
+//            a - 128, and 128 * sum(w) = 32768 goes into the accumulator's initial value.
+//   V pass   out^T[col][row] = sum_k H^T[col][k] Tv[k][row], with H split into its low and high bytes (two products,
+//            recombined as (hi << 8) + lo).  K is only a summation index, so its order is chosen to be the one the
+//            H pass leaves in the registers: lane (col, g) holds rows 4g..4g+3 of both 16-row blocks = its 8 K slots;
+//            the weight operand is laid out to match.  No LDS round trip between the passes, and the result arrives as
+//            4 consecutive pixels of one row per lane = one dword store.
+// Cost per tile: 48 MFMAs and ~300 VALU wave-instructions against ~980 for the VALU form (two passes through LDS).
+struct BlurMfmaTable {
+  uint64_t h[64];      // H pass B operand: byte s of lane (g, n) = w[8 g + s - n - 5]
+  uint64_t v[2][64];   // V pass B operand of output rows 16 nb + (lane & 15)
+};
+constexpr BlurMfmaTable make_blur_mfma_table() {
+  constexpr int BW[7] = {18, 33, 49, 56, 49, 33, 18};
+  BlurMfmaTable t{};
+  for (int l = 0; l < 64; ++l) {
+    const int g = l >> 4, m = l & 15;
+    for (int sl = 0; sl < 8; ++sl) {
+      const int d = 8 * g + sl - m - 5;     // image column 16 j + k feeds output column 16 j + n + 8 - 3 + tap
+      if (d >= 0 && d <= 6) t.h[l] |= (uint64_t)BW[d] << (8 * sl);
+      const int hrow = sl < 4 ? 4 * g + sl : 16 + 4 * g + (sl - 4);
+      for (int nb = 0; nb < 2; ++nb) {
+        const int dv = hrow - (16 * nb + m + 1);   // output row ly reads staged rows ly + 1 .. ly + 7
+        if (dv >= 0 && dv <= 6) t.v[nb][l] |= (uint64_t)BW[dv] << (8 * sl);
+      }
+    }
+  }
+  return t;
+}
+__device__ __attribute__((aligned(16))) const BlurMfmaTable g_blur_mfma_table = make_blur_mfma_table();
+typedef int v4i32_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void blur_tile_mfma(const uint32_t* s_img, uint8_t* __restrict__ blur_out, int n, int H, int W,
+                                               int x0, int y0, int tid) {
+  static_assert(IMG_ROWS == 32 && TW % 16 == 0 && (IMG_DW * 4) % 8 == 0, "blur_tile_mfma: K = the 32 staged rows");
+  const int l = tid & 63, g = l >> 4, m = l & 15;
+  const long bh = (long)g_blur_mfma_table.h[l];
+  const long bv[2] = {(long)g_blur_mfma_table.v[0][l], (long)g_blur_mfma_table.v[1][l]};
+  const uint8_t* img8 = reinterpret_cast<const uint8_t*>(s_img);
+  constexpr unsigned long long SIGN = 0x8080808080808080ull;
+  for (int j = tid >> 6; j < TW / 16; j += NTHREADS / 64) {
+    v4i32_t ch[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const unsigned long long a =
+          *reinterpret_cast<const unsigned long long*>(img8 + (16 * mb + m) * (IMG_DW * 4) + 16 * j + 8 * g) ^ SIGN;
+      const v4i32_t c0 = {32768, 32768, 32768, 32768};
+      ch[mb] = __builtin_amdgcn_mfma_i32_16x16x32_i8((long)a, bh, c0, 0, 0, 0);
+    }
+    // the 8 row sums of this lane (0 .. 65280) -> their low bytes and their high bytes, in K-slot order
+    uint32_t lo[2], hi[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      const uint32_t t0 = __builtin_amdgcn_perm((uint32_t)ch[mb][1], (uint32_t)ch[mb][0], 0x05010400u);
+      const uint32_t t1 = __builtin_amdgcn_perm((uint32_t)ch[mb][3], (uint32_t)ch[mb][2], 0x05010400u);
+      lo[mb] = __builtin_amdgcn_perm(t1, t0, 0x05040100u);
+      hi[mb] = __builtin_amdgcn_perm(t1, t0, 0x07060302u);
+    }
+    const long a_lo = (long)((((unsigned long long)lo[1] << 32) | lo[0]) ^ SIGN);
+    const long a_hi = (long)((((unsigned long long)hi[1] << 32) | hi[0]) ^ SIGN);
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+      const v4i32_t ci = {32768, 32768, 32768, 32768};          // 128 * sum(w)
+      const v4i32_t cl = {65536, 65536, 65536, 65536};          // 128 * sum(w) + the rounding half
+      const v4i32_t chi = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_hi, bv[nb], ci, 0, 0, 0);
+      const v4i32_t clo = __builtin_amdgcn_mfma_i32_16x16x32_i8(a_lo, bv[nb], cl, 0, 0, 0);
+      uint32_t q[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) q[r] = ((uint32_t)chi[r] << 8) + (uint32_t)clo[r];   // < 2^24: the pixel is byte 2
+      const uint32_t v = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0602u) | __builtin_amdgcn_perm(q[3], q[2], 0x06020c0cu);
+      const int ly = 16 * nb + m, gy = y0 + ly, gx = x0 + 16 * j + 4 * g;
+      if (ly < TH && gy < H) {
+        uint8_t* o = blur_out + ((size_t)n * H + gy) * W + gx;
+        if (gx + 3 < W) {
+          __builtin_memcpy(o, &v, 4);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gx + e < W) o[e] = (uint8_t)(v >> (8 * e));
+        }
+      }
+    }
+  }
+}
+
 // One 128 x 24 tile of image n.  HIST (with DETECT): the non-max-suppression survivors of the tile are not listed but
 // counted by score into hist[256 n + score] (vus_fast_threshold_estimate's sample).
 template <bool WRITE_SCORE, bool DETECT, bool BLUR, bool HIST = false>
@@ -168,12 +261,14 @@ __device__ __forceinline__ void fast_tile_body(
     uint8_t* __restrict__ score_out, uint8_t* __restrict__ blur_out,
     uint32_t* __restrict__ cand_keys, int cand_cap, int* __restrict__ cand_count, int* __restrict__ hist,
     int n, int tile, int tiles_x) {
-  __shared__ uint32_t s_img[IMG_ROWS * IMG_DW];
+  __shared__ __attribute__((aligned(8))) uint32_t s_img[IMG_ROWS * IMG_DW];
   __shared__ uint32_t s_score[(WRITE_SCORE || DETECT) ? SC_ROWS * SC_DW : 1];
-  // the strip pre-test's tables (s_mm, s_strip) live in the horizontal-blur buffer, which is not written before pass 2
+  // the strip pre-test's tables (s_mm, s_strip) share the horizontal-blur buffer of the VALU smoothing (not written
+  // before pass 2); the matrix-core smoothing has no such buffer
   constexpr bool STRIP = VUS_FAST_STRIP && (WRITE_SCORE || DETECT);
+  constexpr bool MFMA_BLUR = VUS_BLUR_MFMA && BLUR && IMG_ROWS == 32;
   constexpr int AUX_DW = STRIP ? (IMG_ROWS * IMG_DW + SC_ROWS * SC_DW + 1) / 2 : 2;
-  __shared__ uint32_t s_h[(BLUR && H_ROWS * H_DW > AUX_DW) ? H_ROWS * H_DW : AUX_DW];
+  __shared__ uint32_t s_h[(BLUR && !MFMA_BLUR && H_ROWS * H_DW > AUX_DW) ? H_ROWS * H_DW : AUX_DW];
   __shared__ uint16_t s_work[(WRITE_SCORE || DETECT) ? SC_ROWS * SC_DW * 4 : 2];   // pixels that pass the pre-test
 #if VUS_FAST_STRIP
   uint16_t* const s_mm = reinterpret_cast<uint16_t*>(s_h);       // min | max << 8 of each staged dword
@@ -197,26 +292,39 @@ __device__ __forceinline__ void fast_tile_body(
     const int col = tid % IMG_DW, r0 = tid / IMG_DW;
     const int gx = x0 - 8 + 4 * col;
     const bool fast = gx >= 0 && gx + 3 < W;   // one dword load, aligned or not (odd-width pyramid levels)
-    const int c0 = clampi(gx, 0, W - 1), c1 = clampi(gx + 1, 0, W - 1), c2 = clampi(gx + 2, 0, W - 1),
-              c3 = clampi(gx + 3, 0, W - 1);
+    // tiles whose staged window lies inside the image (all but the frame of edge tiles) need no clamping: one
+    // 32-bit offset per thread and a uniform row stride
+    const bool inside = x0 >= 8 && x0 + TW + 8 <= W && y0 >= 4 && y0 + TH + 4 <= H;
     if (r0 < RPP) {
       // all loads of the thread are issued before the first is used (round 4: the per-row "load, wait, write" chain was
       // five global-memory latencies long); rows past the tile load a valid row again and are not written
       constexpr int NP = (IMG_ROWS + RPP - 1) / RPP;
+      constexpr int LASTP = IMG_ROWS - (NP - 1) * RPP;   // threads with r0 < LASTP have a row in the last pass
       uint32_t v[NP];
-      const uint8_t* rp[NP];
+      if (inside) {
+        const uint32_t off0 = (uint32_t)((y0 - 4 + r0) * pitch + gx);
+        const uint32_t step = (uint32_t)(RPP * pitch);
 #pragma unroll
-      for (int k = 0; k < NP; ++k) rp[k] = im + (size_t)clampi(y0 - 4 + min(r0 + RPP * k, IMG_ROWS - 1), 0, H - 1) * pitch;
-      if (fast) {
-#pragma unroll
-        for (int k = 0; k < NP; ++k) __builtin_memcpy(&v[k], rp[k] + gx, 4);
+        for (int k = 0; k < NP - 1; ++k) __builtin_memcpy(&v[k], im + (off0 + (uint32_t)k * step), 4);
+        v[NP - 1] = 0u;
+        if (r0 < LASTP) __builtin_memcpy(&v[NP - 1], im + (off0 + (uint32_t)(NP - 1) * step), 4);
       } else {
-        uint8_t q[NP][4];
+        const uint8_t* rp[NP];
 #pragma unroll
-        for (int k = 0; k < NP; ++k) { q[k][0] = rp[k][c0]; q[k][1] = rp[k][c1]; q[k][2] = rp[k][c2]; q[k][3] = rp[k][c3]; }
+        for (int k = 0; k < NP; ++k) rp[k] = im + (size_t)clampi(y0 - 4 + min(r0 + RPP * k, IMG_ROWS - 1), 0, H - 1) * pitch;
+        if (fast) {
 #pragma unroll
-        for (int k = 0; k < NP; ++k)
-          v[k] = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 8) | ((uint32_t)q[k][2] << 16) | ((uint32_t)q[k][3] << 24);
+          for (int k = 0; k < NP; ++k) __builtin_memcpy(&v[k], rp[k] + gx, 4);
+        } else {
+          const int c0 = clampi(gx, 0, W - 1), c1 = clampi(gx + 1, 0, W - 1), c2 = clampi(gx + 2, 0, W - 1),
+                    c3 = clampi(gx + 3, 0, W - 1);
+          uint8_t q[NP][4];
+#pragma unroll
+          for (int k = 0; k < NP; ++k) { q[k][0] = rp[k][c0]; q[k][1] = rp[k][c1]; q[k][2] = rp[k][c2]; q[k][3] = rp[k][c3]; }
+#pragma unroll
+          for (int k = 0; k < NP; ++k)
+            v[k] = (uint32_t)q[k][0] | ((uint32_t)q[k][1] << 8) | ((uint32_t)q[k][2] << 16) | ((uint32_t)q[k][3] << 24);
+        }
       }
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
@@ -256,21 +364,26 @@ __device__ __forceinline__ void fast_tile_body(
     // dark side.  Measured on the configs[1] frames: 9.0 % of the strips pass at the adaptive threshold where 8.2 % hold
     // a pixel that passes the per-pixel test, 47 % against 45 % at fast_threshold 10.  The per-pixel test then runs on
     // the listed strips only.
-    // all iterations are evaluated first and listed with ONE LDS atomic per wave
-    constexpr int NIT = (SC_ROWS * SC_DW + NTHREADS - 1) / NTHREADS;
+    // Thread = fixed strip column, S_RPP rows per pass (no per-item division; the LDS addresses of a pass differ from
+    // the first one's by constants).  All passes are evaluated first and listed with ONE LDS atomic per wave.
+    constexpr int S_RPP = NTHREADS / SC_DW;                       // 7 rows of 34 strips per pass
+    constexpr int NIT = (SC_ROWS + S_RPP - 1) / S_RPP;
+    const int sr0 = tid / SC_DW, ss = tid - sr0 * SC_DW;
+    const int gx = x0 - 4 + 4 * ss;
+    const bool col_ok = sr0 < S_RPP && gx + 3 >= 3 && gx < W - 3;
+    const int ci0 = (sr0 + 3) * IMG_DW + ss;
     unsigned long long bal[NIT];
     bool pass[NIT];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-      const int idx = it * NTHREADS + tid;
+      const int sr = sr0 + it * S_RPP;
       pass[it] = false;
-      if (idx < SC_ROWS * SC_DW) {
-        const int sr = idx / SC_DW, ss = idx - sr * SC_DW;
-        const int gy = y0 - 1 + sr, gx = x0 - 4 + 4 * ss;
-        if (gy >= 3 && gy < H - 3 && gx + 3 >= 3 && gx < W - 3) {
-          const int ci = (sr + 3) * IMG_DW + ss;
+      if (sr0 < S_RPP && sr < SC_ROWS) {
+        const int gy = y0 - 1 + sr;
+        if (col_ok && gy >= 3 && gy < H - 3) {
+          const int ci = ci0 + it * S_RPP * IMG_DW;
           const int ma = s_mm[ci], mb = s_mm[ci + 1], mc = s_mm[ci + 2];
-          const int mn = s_mm[sr * IMG_DW + ss + 1], ms = s_mm[(sr + 6) * IMG_DW + ss + 1];
+          const int mn = s_mm[ci + 1 - 3 * IMG_DW], ms = s_mm[ci + 1 + 3 * IMG_DW];
           const uint32_t b = s_img[ci + 1];
           const int b0 = byte_of(b, 0), b3 = byte_of(b, 3);
           const int pmin = mb & 0xFF, pmax = mb >> 8;
@@ -278,7 +391,7 @@ __device__ __forceinline__ void fast_tile_body(
           const int lo = max(min(mn & 0xFF, ms & 0xFF), min3i(ma & 0xFF, mc & 0xFF, min(b0, b3)));
           pass[it] = hi > pmin + thr || lo < pmax - thr;
         }
-        s_score[idx] = 0u;
+        s_score[sr * SC_DW + ss] = 0u;
       }
       bal[it] = __ballot(pass[it]);
     }
@@ -293,7 +406,7 @@ __device__ __forceinline__ void fast_tile_body(
       for (int it = 0; it < NIT; ++it) {
         if (pass[it])
           s_strip[base + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[it] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[it], 0))] =
-              (uint16_t)(it * NTHREADS + tid);
+              (uint16_t)((sr0 + it * S_RPP) * SC_DW + ss);
         base += __popcll(bal[it]);
       }
     }
@@ -388,10 +501,11 @@ __device__ __forceinline__ void fast_tile_body(
       *reinterpret_cast<uint2*>(&s_h[hr * H_DW + 2 * hs]) = out;
     }
   };
-  if (BLUR && !STRIP) blur_rows();
+  if (BLUR && !MFMA_BLUR && !STRIP) blur_rows();
+  if (MFMA_BLUR) blur_tile_mfma(s_img, blur_out, n, H, W, x0, y0, tid);   // reads the staged tile only: no barrier of its own
   __syncthreads();
 
-  if (BLUR && STRIP) blur_rows();   // after the barrier: its buffer held the strip tables until here
+  if (BLUR && !MFMA_BLUR && STRIP) blur_rows();   // after the barrier: its buffer held the strip tables until here
   if (WRITE_SCORE || DETECT) {
     // Pass 2 -- exact FAST score of the survivors, one pixel per lane.  The 12-byte row windows are
     // re-aligned with v_alignbyte so that the pixel sits at byte 4 and the strip code (E = 0) applies.
@@ -433,7 +547,7 @@ __device__ __forceinline__ void fast_tile_body(
       }
     }
   }
-  if (BLUR) {
+  if (BLUR && !MFMA_BLUR) {
     constexpr int BW[7] = {18, 33, 49, 56, 49, 33, 18};
     for (int idx = tid; idx < TH * STRIPS; idx += NTHREADS) {
       const int ly = idx / STRIPS, ls = idx - ly * STRIPS;
@@ -776,6 +890,28 @@ __device__ __forceinline__ int wave_sum_i32(int v) {
   return __builtin_amdgcn_readlane(v, 63);
 }
 
+// Maximum of a 64-bit key over lanes 0..31 with DPP row shifts (round 4: the five __shfl_xor butterfly steps were ten
+// ds_bpermute round trips in orient_rbrief's dependent chain).  A lane whose DPP source does not exist keeps its own
+// value (old = src, bound_ctrl off), which a maximum does not mind.  Returned wave-uniform from lane 31.
+template <int CTRL>
+__device__ __forceinline__ long long dpp_max_step_i64(long long key) {
+  const int lo = (int)(uint32_t)key, hi = (int)(key >> 32);
+  const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  const long long ok = (long long)(((unsigned long long)(uint32_t)ohi << 32) | (uint32_t)olo);
+  return ok > key ? ok : key;
+}
+__device__ __forceinline__ long long wave32_max_i64(long long key) {
+  key = dpp_max_step_i64<0x111>(key);   // row_shr:1
+  key = dpp_max_step_i64<0x112>(key);   // row_shr:2
+  key = dpp_max_step_i64<0x114>(key);   // row_shr:4
+  key = dpp_max_step_i64<0x118>(key);   // row_shr:8  -> lane 15 of a row holds the row's maximum
+  key = dpp_max_step_i64<0x142>(key);   // row_bcast:15 -> lane 31 holds the maximum of lanes 0..31
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 31);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), 31);
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
 __device__ const uint8_t kDiscUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 // Rotated test pattern re-laid for the kernel: [bin][lane][word] = the two patch byte offsets
@@ -914,13 +1050,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
       long long key = lane < VUS_N_ANGLE_BINS
                           ? ((long long)m10 * VUS_ANGLE_COS[lane] + (long long)m01 * VUS_ANGLE_SIN[lane]) * 32 + (31 - lane)
                           : (long long)(-0x7FFFFFFFFFFFFFFFll - 1);
-#pragma unroll
-      for (int o = 16; o > 0; o >>= 1) {   // the 30 bins live in lanes 0..29: 32 lanes suffice
-        const long long ok = __shfl_xor(key, o);
-        key = ok > key ? ok : key;
-      }
-      int bin = 31 - (int)(key & 31);
-      bin = __builtin_amdgcn_readfirstlane(bin);
+      key = wave32_max_i64(key);           // the 30 bins live in lanes 0..29
+      const int bin = 31 - (int)(key & 31);
       // this lane's four tests of the bin's pattern, as patch byte offsets: one 16-byte load
       const uint4 to = reinterpret_cast<const uint4*>(g_rot_off_table.v)[bin * 64 + lane];
       const uint8_t* c = blur8 + BR_R * (4 * BR_DW) + BR_R + sh_blur;   // the keypoint inside the patch
