@@ -12,7 +12,10 @@ for d in [a for a in sys.argv[1:] if a.startswith("/") or a.startswith("gpurun")
             k = re.sub(r"\(.*", "", k)
             out[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 for k, cs in out.items():
-    print(k)
+    try:
+        print(k)
+    except BrokenPipeError:
+        break
     for c, v in sorted(cs.items()):
         print(f"   {c:28s} n={len(v):4d} mean={sum(v)/len(v):.4g}")
 

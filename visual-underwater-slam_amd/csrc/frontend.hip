@@ -805,7 +805,6 @@ constexpr int OR_ROWS = 2 * OR_R + 1;       // 31
 #endif
 constexpr int OR_VW = VUS_OR_VW;               // dwords per lane and load
 constexpr int OR_DW = OR_VW == 4 ? 12 : 10;    // 36 bytes cover x-15..x+15 from an aligned start; a multiple of OR_VW is loaded
-constexpr int OR_MW = 10;                   // dword columns that can hold disc pixels
 constexpr int BR_R = VUS_RBRIEF_REACH;      // 18
 constexpr int BR_ROWS = 2 * BR_R + 1;       // 37
 constexpr int BR_DW = OR_VW == 4 ? 12 : 10;    // 40 bytes cover x-18..x+18 from an aligned start
@@ -835,13 +834,14 @@ struct PatchRegs {
   static constexpr int N = ROWS * HW;
   static constexpr int ITERS = (N + 63) / 64;
   vec_t v[ITERS];
-  int off[ITERS];   // byte offset of this lane's vectors inside an in-image patch (fixed per kernel)
+  uint32_t off[ITERS];   // byte offset of this lane's vectors inside an in-image patch (fixed per kernel); unsigned:
+                         // scalar base + zero-extended 32-bit lane offset is an addressing mode of global_load
 
   __device__ __forceinline__ void init(int pitch, int lane) {
 #pragma unroll
     for (int u = 0; u < ITERS; ++u) {
       const int t = min(lane + 64 * u, N - 1);
-      off[u] = (t / HW) * pitch + 4 * VW * (t % HW);
+      off[u] = (uint32_t)((t / HW) * pitch + 4 * VW * (t % HW));
     }
   }
   __device__ __forceinline__ void load(const uint8_t* __restrict__ src, int H, int W, int pitch, int y, int x,
@@ -851,7 +851,7 @@ struct PatchRegs {
     if (inside) {   // wave-uniform
       const uint8_t* base = src + (size_t)(y - RADIUS) * pitch + xa;
 #pragma unroll
-      for (int u = 0; u < ITERS; ++u) v[u] = *reinterpret_cast<const vec_t*>(base + off[u]);
+      for (int u = 0; u < ITERS; ++u) v[u] = *reinterpret_cast<const vec_t*>(base + (size_t)off[u]);
     } else {        // replicate-clamped, byte by byte (keypoints near the image edge)
 #pragma unroll
       for (int u = 0; u < ITERS; ++u) {
@@ -878,38 +878,52 @@ struct PatchRegs {
   }
 };
 
-// Wave-wide integer sum with DPP row shifts / broadcasts (VALU latency instead of six LDS-crossbar
-// round trips); the total is read from lane 63 and returned wave-uniform.
-__device__ __forceinline__ int wave_sum_i32(int v) {
-  v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
-  v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
-  v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xe, true);   // row_shr:4, banks 1-3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xc, true);   // row_shr:8, banks 2-3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
-  v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
-  return __builtin_amdgcn_readlane(v, 63);
+// Cross-lane helpers of orient_rbrief (round 4, second pass).  A wave works on EIGHT keypoints at once; the per-lane
+// partial sums of their centroid moments (16 values) are folded with a reduce-scatter instead of 16 full wave
+// reductions: v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / odd-even rows of TWO registers in one
+// instruction, so that one add folds two values at once; then one row_ror:8 and three 8-lane all-reduce steps.
+// After it the eight lanes 8g..8g+7 hold the totals of keypoint g.
+__device__ __forceinline__ int fold32(int x, int y) {   // lanes < 32: x[l] + x[l+32];  lanes >= 32: y[l-32] + y[l]
+  auto r = __builtin_amdgcn_permlane32_swap((uint32_t)x, (uint32_t)y, false, false);
+  return (int)(r[0] + r[1]);
 }
-
-// Maximum of a 64-bit key over lanes 0..31 with DPP row shifts (round 4: the five __shfl_xor butterfly steps were ten
-// ds_bpermute round trips in orient_rbrief's dependent chain).  A lane whose DPP source does not exist keeps its own
-// value (old = src, bound_ctrl off), which a maximum does not mind.  Returned wave-uniform from lane 31.
+__device__ __forceinline__ int fold16(int x, int y) {   // rows 0, 2: x's row pair summed;  rows 1, 3: y's row pair summed
+  auto r = __builtin_amdgcn_permlane16_swap((uint32_t)x, (uint32_t)y, false, false);
+  return (int)(r[0] + r[1]);
+}
 template <int CTRL>
-__device__ __forceinline__ long long dpp_max_step_i64(long long key) {
-  const int lo = (int)(uint32_t)key, hi = (int)(key >> 32);
-  const int olo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-  const int ohi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
-  const long long ok = (long long)(((unsigned long long)(uint32_t)ohi << 32) | (uint32_t)olo);
+__device__ __forceinline__ int dpp_i32(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true); }
+constexpr int DPP_ROW_ROR8 = 0x128, DPP_HALF_MIRROR = 0x141, DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E;
+__device__ __forceinline__ int fold8(int x, int y, bool upper8) {   // lanes with bit 3 clear: x over lane pairs (l, l+8); set: y
+  const int keep = upper8 ? y : x, give = upper8 ? x : y;
+  return keep + dpp_i32<DPP_ROW_ROR8>(give);
+}
+__device__ __forceinline__ int allsum8(int v) {   // every lane: the sum over its group of eight lanes
+  v += dpp_i32<DPP_HALF_MIRROR>(v);
+  v += dpp_i32<DPP_QUAD_XOR1>(v);
+  v += dpp_i32<DPP_QUAD_XOR2>(v);
+  return v;
+}
+template <int CTRL>
+__device__ __forceinline__ long long dpp_max_i64(long long key) {   // every source lane of these patterns exists
+  const int lo = dpp_i32<CTRL>((int)(uint32_t)key), hi = dpp_i32<CTRL>((int)(key >> 32));
+  const long long ok = (long long)(((unsigned long long)(uint32_t)hi << 32) | (uint32_t)lo);
   return ok > key ? ok : key;
 }
-__device__ __forceinline__ long long wave32_max_i64(long long key) {
-  key = dpp_max_step_i64<0x111>(key);   // row_shr:1
-  key = dpp_max_step_i64<0x112>(key);   // row_shr:2
-  key = dpp_max_step_i64<0x114>(key);   // row_shr:4
-  key = dpp_max_step_i64<0x118>(key);   // row_shr:8  -> lane 15 of a row holds the row's maximum
-  key = dpp_max_step_i64<0x142>(key);   // row_bcast:15 -> lane 31 holds the maximum of lanes 0..31
-  const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, 31);
-  const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(key >> 32), 31);
-  return (long long)(((unsigned long long)hi << 32) | lo);
+__device__ __forceinline__ long long allmax8_i64(long long key) {
+  key = dpp_max_i64<DPP_HALF_MIRROR>(key);
+  key = dpp_max_i64<DPP_QUAD_XOR1>(key);
+  key = dpp_max_i64<DPP_QUAD_XOR2>(key);
+  return key;
+}
+
+// v_writelane_b32: one lane of a register takes a wave-uniform value (no builtin in this compiler).  Value and lane
+// select are both scalar registers and gfx9 encodings read ONE over the constant bus: the select goes through M0, which
+// the instruction accepts as its lane operand.  M0 is written and consumed inside the one asm statement; no kernel of
+// this file gives the compiler a reason to keep a value of its own there (no LDS-DMA, no indirect register indexing).
+__device__ __forceinline__ uint32_t writelane_u32(uint32_t reg, uint32_t value, int lane_sel) {
+  asm("s_mov_b32 m0, %2\n\tv_writelane_b32 %0, %1, m0" : "+v"(reg) : "s"(value), "s"(lane_sel));   // M0 is a reserved register: not listable as a clobber
+  return reg;
 }
 
 __device__ const uint8_t kDiscUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
@@ -935,19 +949,34 @@ __device__ __attribute__((aligned(16))) const RotOffTable g_rot_off_table = make
 #ifndef VUS_OR_WPE
 #define VUS_OR_WPE 4
 #endif
+#ifndef VUS_OR_GRP
+#define VUS_OR_GRP 4
+#endif
+constexpr int OR_GRP = VUS_OR_GRP;   // centroid patches of this many keypoints are in flight together (4 or 8)
+static_assert(OR_VW == 2 && OR_KP_PER_WAVE == 8, "orient_rbrief_kernel is written for dwordx2 patch loads and 8 keypoints per wave");
+constexpr int OR_NV = OR_ROWS * (OR_DW / OR_VW);   // 155 dwordx2 vectors of a centroid patch
+constexpr int OR_WT = 192;                         // weight entries per byte alignment: one per vector, padded to 3 x 64 lanes
+
+// One wave = eight consecutive keypoints of one image, in two phases.
+//  A. orientation of all eight: the 31-row image patches arrive in registers (3 dwordx2 per lane and keypoint, up to
+//     12 in flight) and are multiplied right there with the disc weights (v_dot4_u32_u8; the weights of a lane's two
+//     dwords are ONE ds_read_b128): no LDS round trip for the patch.  Per-lane partial moments of the eight keypoints
+//     -> reduce-scatter (above) -> lane 8g + j holds m10 / m01 of keypoint g and ranks bins 4j .. 4j+3.
+//  B. descriptors, keypoint by keypoint: the 37-row patch of the smoothed image goes through LDS (double-buffered; the
+//     next keypoint's rows and its bin's test offsets are in flight meanwhile), 8 byte reads + 4 compares per lane; the
+//     ballots are written into lanes 4k + w of one register pair, so the eight descriptors leave in ONE 256-byte store.
+// Round 4 first pass: one keypoint at a time, 232 vector instructions per keypoint (2.67 ms per 1000 stereo frames).
 template <bool EXACT>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE, 8))) void orient_rbrief_kernel(
     const uint8_t* __restrict__ img, const uint8_t* __restrict__ blur, int H, int W, int pitch,
     const uint32_t* __restrict__ kp_keys, const int* __restrict__ kp_count, int max_kp,
     uint64_t* __restrict__ desc_out, uint8_t* __restrict__ angle_out, int n_img, int chunks_per_img) {
-  __shared__ __attribute__((aligned(8))) uint32_t s_raw[4][OR_ROWS * OR_DW];
-  __shared__ __attribute__((aligned(8))) uint32_t s_blur[4][BR_ROWS * BR_DW];
-  // centroid weights per patch dword, for the 4 possible byte alignments of the patch:
-  // s_wx = (dx + 15) inside the disc else 0 (u8 x 4), s_wm = 1 inside the disc else 0
-  __shared__ uint32_t s_wx[4 * OR_ROWS * OR_MW];
-  __shared__ uint32_t s_wm[4 * OR_ROWS * OR_MW];
+  // centroid weights per patch vector (two dwords), for the 4 possible byte alignments of the patch:
+  // .x/.y = (dx + 15) inside the disc else 0 (u8 x 4) of the two dwords, .z/.w = 1 inside the disc else 0
+  __shared__ uint4 s_w[4 * OR_WT];
+  __shared__ __attribute__((aligned(8))) uint32_t s_blur[4][2][BR_ROWS * BR_DW];
   const int lane = threadIdx.x & 63;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   // XCD-aware block -> (image, chunk) map: workgroups are dealt round-robin over the 8 XCDs, so all
   // chunks of one image go to blocks with equal (blockIdx % 8): the image's two 0.9 MB planes then
   // stay in ONE XCD's 4 MiB L2 while its 2000 patches are gathered (placement affects speed only).
@@ -955,126 +984,163 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
   const int n = (slot / chunks_per_img) * 8 + xcd;
   const int chunk = slot - (slot / chunks_per_img) * chunks_per_img;
   if (n >= n_img) return;
-  for (int e = threadIdx.x; e < 4 * OR_ROWS * OR_MW; e += 256) {
-    const int sh = e / (OR_ROWS * OR_MW), t = e - sh * (OR_ROWS * OR_MW);
-    const int r = t / OR_MW, c = t - r * OR_MW;
-    const int dy = r - OR_R, um = kDiscUmax[dy < 0 ? -dy : dy];
-    uint32_t wx = 0, wm = 0;
+  for (int e = threadIdx.x; e < 4 * OR_WT; e += 256) {
+    const int sh = e / OR_WT, t = e - sh * OR_WT;
+    uint32_t w[4] = {0, 0, 0, 0};
+    if (t < OR_NV) {
+      const int r = t / (OR_DW / 2), c = t - r * (OR_DW / 2);
+      const int dy = r - OR_R, um = kDiscUmax[dy < 0 ? -dy : dy];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const int dx = 4 * c + b - sh - OR_R;
-      if (dx >= -um && dx <= um) {
-        wx |= (uint32_t)(dx + OR_R) << (8 * b);
-        wm |= 1u << (8 * b);
-      }
+      for (int d = 0; d < 2; ++d)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          const int dx = 4 * (2 * c + d) + b - sh - OR_R;
+          if (dx >= -um && dx <= um) {
+            w[d] |= (uint32_t)(dx + OR_R) << (8 * b);
+            w[2 + d] |= 1u << (8 * b);
+          }
+        }
     }
-    s_wx[e] = wx;
-    s_wm[e] = wm;
+    s_w[e] = make_uint4(w[0], w[1], w[2], w[3]);
   }
   const uint8_t* im = img + (size_t)n * H * pitch;
   const uint8_t* bl = blur + (size_t)n * H * W;
-  const int count = kp_count[n];
-  const uint8_t* blur8 = reinterpret_cast<const uint8_t*>(s_blur[wave]);
-  // this lane's share of the centroid patch: row offsets dy of its dwords
-  constexpr int MOM_ITERS = (OR_ROWS * OR_MW + 63) / 64;   // the disc lives in the first OR_MW dword columns
-  int mom_dy[MOM_ITERS], mom_idx[MOM_ITERS];
+  const int base_i = (chunk * 4 + wave) * OR_KP_PER_WAVE;       // this wave's keypoints: base_i .. base_i + 7
+  const int n_live = clampi(min(kp_count[n], max_kp) - base_i, 0, OR_KP_PER_WAVE);
+  int my_y = 0, my_x = 0;                                         // lane k < 8: position of keypoint k
+  if (lane < n_live) {
+    const uint32_t pos = kp_keys[(size_t)n * max_kp + base_i + lane] & VUS_KEY_POS_MASK;
+    my_y = (int)(pos / (uint32_t)W);
+    my_x = (int)(pos - (uint32_t)my_y * (uint32_t)W);
+  }
+  // the bins this lane ranks in phase A: 4 (lane & 7) + q
+  int bin_cos[4], bin_sin[4];
 #pragma unroll
-  for (int u = 0; u < MOM_ITERS; ++u) {
-    const int t = min(lane + 64 * u, OR_ROWS * OR_MW - 1);
-    mom_dy[u] = t / OR_MW - OR_R;
-    mom_idx[u] = (t / OR_MW) * OR_DW + t % OR_MW;
+  for (int q = 0; q < 4; ++q) {
+    const int bq = min(4 * (lane & 7) + q, VUS_N_ANGLE_BINS - 1);
+    bin_cos[q] = VUS_ANGLE_COS[bq];
+    bin_sin[q] = VUS_ANGLE_SIN[bq];
   }
-  // software pipeline over this wave's keypoints: the patch loads of keypoint it+1 are in flight
-  // while keypoint it is reduced out of LDS
-  auto kp_xy = [&](int it, int& i, bool& live, int& y, int& x) {
-    i = (chunk * OR_KP_PER_WAVE + it) * 4 + wave;
-    live = i < count && i < max_kp;
-    y = 0; x = 0;
-    if (live) {
-      const uint32_t pos = kp_keys[(size_t)n * max_kp + i] & VUS_KEY_POS_MASK;
-      y = (int)(pos / (uint32_t)W);
-      x = (int)(pos - (uint32_t)y * (uint32_t)W);
-    }
-  };
-  PatchRegs<OR_R, OR_DW, OR_VW, EXACT> pr;
+  PatchRegs<OR_R, OR_DW, OR_VW, EXACT> pr[OR_GRP];
   PatchRegs<BR_R, BR_DW, OR_VW, EXACT> pb;
-  pr.init(pitch, lane);
+#pragma unroll
+  for (int kk = 0; kk < OR_GRP; ++kk) pr[kk].init(pitch, lane);
   pb.init(W, lane);
-  int i, y, x;
-  bool live;
-  kp_xy(0, i, live, y, x);
-  if (live) {
-    pr.load(im, H, W, pitch, y, x, lane);
-    pb.load(bl, H, W, W, y, x, lane);
+  int mom_dy[3];
+#pragma unroll
+  for (int u = 0; u < 3; ++u) mom_dy[u] = min(lane + 64 * u, OR_NV - 1) / (OR_DW / 2) - OR_R;
+  __syncthreads();   // the weight table is complete (the only workgroup-level synchronisation of the kernel)
+  if (n_live == 0) {   // wave-uniform: nothing but defined contents for the unused slots
+    if (lane < 4 * OR_KP_PER_WAVE && base_i + (lane >> 2) < max_kp) desc_out[((size_t)n * max_kp + base_i) * 4 + lane] = 0;
+    if (lane < OR_KP_PER_WAVE && base_i + lane < max_kp) angle_out[(size_t)n * max_kp + base_i + lane] = 0;
+    return;
   }
-  __syncthreads();   // the weight tables are complete
-  // Each wave owns its two LDS patches: inside the loop only wave-level ordering is needed (LDS
-  // operations of one wave execute in order), so the four waves of a workgroup run unsynchronised.
-  for (int it = 0; it < OR_KP_PER_WAVE; ++it) {
-    if (live) {
-      pr.store(s_raw[wave], lane);
-      pb.store(s_blur[wave], lane);
+
+  // ---- phase A: centroid moments of the eight keypoints, four at a time
+  int pa[8], pq[8];   // per-lane partials of m10 and m01
+#pragma unroll
+  for (int g = 0; g < 8 / OR_GRP; ++g) {
+#pragma unroll
+    for (int kk = 0; kk < OR_GRP; ++kk) {
+      const int k = OR_GRP * g + kk;
+#ifndef VUS_OR_EXP_NORAW
+      if (k < n_live)
+        pr[kk].load(im, H, W, pitch, __builtin_amdgcn_readlane(my_y, k), __builtin_amdgcn_readlane(my_x, k), lane);
+#else
+      for (int u = 0; u < 3; ++u) pr[kk].v[u] = typename PatchVec<OR_VW>::type{(uint32_t)lane, (uint32_t)k};
+#endif
+    }
+    if (g == 8 / OR_GRP - 1)   // the first descriptor patch joins the queue behind the last centroid patches
+      pb.load(bl, H, W, W, __builtin_amdgcn_readlane(my_y, 0), __builtin_amdgcn_readlane(my_x, 0), lane);
+#pragma unroll
+    for (int kk = 0; kk < OR_GRP; ++kk) {
+      const int k = OR_GRP * g + kk;
+      pa[k] = 0;
+      pq[k] = 0;
+      if (k < n_live) {
+        const int sh = EXACT ? 0 : (__builtin_amdgcn_readlane(my_x, k) - OR_R) & 3;
+        const uint4* wt = s_w + sh * OR_WT + lane;
+        uint32_t sx = 0;
+        int si = 0, sy = 0;
+#pragma unroll
+        for (int u = 0; u < 3; ++u) {
+          const uint4 w = wt[64 * u];
+          sx = __builtin_amdgcn_udot4(pr[kk].v[u][0], w.x, sx, false);
+          sx = __builtin_amdgcn_udot4(pr[kk].v[u][1], w.y, sx, false);
+          uint32_t rs = __builtin_amdgcn_udot4(pr[kk].v[u][0], w.z, 0u, false);
+          rs = __builtin_amdgcn_udot4(pr[kk].v[u][1], w.w, rs, false);
+          si += (int)rs;
+          sy += mom_dy[u] * (int)rs;
+        }
+        pa[k] = (int)sx - OR_R * si;   // sum dx I over this lane's pixels
+        pq[k] = sy;                    // sum dy I
+      }
+    }
+  }
+  // reduce-scatter: afterwards the lanes of group g = lane / 8 hold the moments of keypoint g
+  int m10, m01;
+  {
+    const bool up8 = (lane & 8) != 0;
+    int c[4], d[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = fold32(pa[j], pa[j + 4]);        // lanes < 32: keypoint j, else j + 4
+#pragma unroll
+    for (int j = 0; j < 2; ++j) d[j] = fold16(c[j], c[j + 2]);          // row r: keypoint j + 2 r
+    m10 = allsum8(fold8(d[0], d[1], up8));                              // group g: keypoint g
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = fold32(pq[j], pq[j + 4]);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) d[j] = fold16(c[j], c[j + 2]);
+    m01 = allsum8(fold8(d[0], d[1], up8));
+  }
+  // nearest bin direction = largest projection, first maximum wins (integer, exact):
+  // |prj| < 2^38, so (prj << 5) | (31 - bin) orders by projection, then by lowest bin, in one 64-bit max
+  int my_bin;
+  {
+    long long best = (long long)(-0x7FFFFFFFFFFFFFFFll - 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int bq = 4 * (lane & 7) + q;
+      long long key = ((long long)m10 * bin_cos[q] + (long long)m01 * bin_sin[q]) * 32 + (31 - bq);
+      if (bq >= VUS_N_ANGLE_BINS) key = (long long)(-0x7FFFFFFFFFFFFFFFll - 1);
+      best = key > best ? key : best;
+    }
+    best = allmax8_i64(best);
+    my_bin = 31 - (int)(best & 31);   // a keypoint that is not live has zero moments: bin 0
+  }
+  if ((lane & 7) == 0 && base_i + (lane >> 3) < max_kp) angle_out[(size_t)n * max_kp + base_i + (lane >> 3)] = (uint8_t)my_bin;
+
+  // ---- phase B: the descriptors
+  uint32_t wlo = 0, whi = 0;   // lane 4k + w: word w of keypoint k
+  const uint4* rot = reinterpret_cast<const uint4*>(g_rot_off_table.v) + lane;
+  uint4 to = rot[__builtin_amdgcn_readlane(my_bin, 0) * 64];
+  for (int k = 0; k < n_live; ++k) {   // scalar loop
+    uint32_t* patch = s_blur[wave][k & 1];
+    pb.store(patch, lane);
+    const uint4 cto = to;
+    const int cx = __builtin_amdgcn_readlane(my_x, k);
+    if (k + 1 < n_live) {
+#ifndef VUS_OR_EXP_NOBLUR
+      pb.load(bl, H, W, W, __builtin_amdgcn_readlane(my_y, k + 1), __builtin_amdgcn_readlane(my_x, k + 1), lane);
+#endif
+      to = rot[__builtin_amdgcn_readlane(my_bin, 8 * (k + 1)) * 64];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // this wave's LDS operations execute in order
+    const int sh_blur = EXACT ? 0 : (cx - BR_R) & 3;   // patch column of x - radius
+    const uint8_t* c = reinterpret_cast<const uint8_t*>(patch) + BR_R * (4 * BR_DW) + BR_R + sh_blur;   // the keypoint inside the patch
+    const uint32_t tw[4] = {cto.x, cto.y, cto.z, cto.w};
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int a = c[(int16_t)(tw[w] & 0xFFFFu)];
+      const int b = c[(int16_t)(tw[w] >> 16)];
+      const uint64_t word = __ballot(a < b);  // lane l supplies bit l of word w
+      wlo = writelane_u32(wlo, (uint32_t)word, 4 * k + w);
+      whi = writelane_u32(whi, (uint32_t)(word >> 32), 4 * k + w);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-    const int ci = i, cx = x;
-    const bool clive = live;
-    if (it + 1 < OR_KP_PER_WAVE) {
-      kp_xy(it + 1, i, live, y, x);
-      if (live) {
-        pr.load(im, H, W, pitch, y, x, lane);
-        pb.load(bl, H, W, W, y, x, lane);
-      }
-    }
-    if (clive) {
-      const int sh_raw = EXACT ? 0 : (cx - OR_R) & 3, sh_blur = EXACT ? 0 : (cx - BR_R) & 3;   // patch column of x-radius
-      // centroid moments, 4 pixels per v_dot4_u32_u8:  sum (dx+15) I,  sum I,  sum dy I
-      int sx = 0, si = 0, sy = 0;
-#pragma unroll
-      for (int u = 0; u < MOM_ITERS; ++u) {
-        const int t = lane + 64 * u;
-        if (t < OR_ROWS * OR_MW) {
-          const uint32_t v = s_raw[wave][mom_idx[u]];
-          const int e = sh_raw * (OR_ROWS * OR_MW) + t;
-          sx = (int)__builtin_amdgcn_udot4(v, s_wx[e], (uint32_t)sx, false);
-          const int rs = (int)__builtin_amdgcn_udot4(v, s_wm[e], 0u, false);
-          si += rs;
-          sy += mom_dy[u] * rs;
-        }
-      }
-      sx = wave_sum_i32(sx);
-      si = wave_sum_i32(si);
-      const int m01 = wave_sum_i32(sy);
-      const int m10 = sx - OR_R * si;
-      // nearest bin direction = largest projection, first maximum wins (integer, exact)
-      // |prj| < 2^38, so (prj << 5) | (31 - bin) orders by projection, then by lowest bin, in one 64-bit max
-      long long key = lane < VUS_N_ANGLE_BINS
-                          ? ((long long)m10 * VUS_ANGLE_COS[lane] + (long long)m01 * VUS_ANGLE_SIN[lane]) * 32 + (31 - lane)
-                          : (long long)(-0x7FFFFFFFFFFFFFFFll - 1);
-      key = wave32_max_i64(key);           // the 30 bins live in lanes 0..29
-      const int bin = 31 - (int)(key & 31);
-      // this lane's four tests of the bin's pattern, as patch byte offsets: one 16-byte load
-      const uint4 to = reinterpret_cast<const uint4*>(g_rot_off_table.v)[bin * 64 + lane];
-      const uint8_t* c = blur8 + BR_R * (4 * BR_DW) + BR_R + sh_blur;   // the keypoint inside the patch
-      const uint32_t tw[4] = {to.x, to.y, to.z, to.w};
-      uint64_t word[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const int a = c[(int16_t)(tw[w] & 0xFFFFu)];
-        const int b = c[(int16_t)(tw[w] >> 16)];
-        word[w] = __ballot(a < b);  // lane l supplies bit l of word w
-      }
-      if (lane == 0) {
-        uint64_t* d = desc_out + ((size_t)n * max_kp + ci) * 4;
-        d[0] = word[0]; d[1] = word[1]; d[2] = word[2]; d[3] = word[3];
-        angle_out[(size_t)n * max_kp + ci] = (uint8_t)bin;
-      }
-    } else if (ci < max_kp) {   // unused slot: defined contents
-      uint64_t* d = desc_out + ((size_t)n * max_kp + ci) * 4;
-      if (lane < 4) d[lane] = 0;
-      if (lane == 0) angle_out[(size_t)n * max_kp + ci] = 0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the patch is read before the next store overwrites it
   }
+  if (lane < 4 * OR_KP_PER_WAVE && base_i + (lane >> 2) < max_kp)
+    desc_out[((size_t)n * max_kp + base_i) * 4 + lane] = ((uint64_t)whi << 32) | wlo;
 }
 
 // ---------------------------------------------------------------------------------------------
