@@ -159,8 +159,10 @@ def _pipeline_oracle(oracle, img, max_kp):
     return kp, kc, blur, desc, ang
 
 
-@pytest.mark.parametrize("shape,max_kp", [((160, 224), 300), ((720, 1280), 2000)])
+@pytest.mark.parametrize("shape,max_kp", [((160, 224), 300), ((720, 1280), 2000), ((100, 236), 150), ((97, 203), 120)])
 def test_orient_rbrief_bit_exact(gpu, oracle, shape, max_kp):
+    """(97, 203): rows not dword aligned (exact-start patch loads); max_kp values that leave the last wave's batch of
+    eight keypoints partly empty."""
     import visual_underwater_slam_amd._lib as L
     H, W = shape
     img = synth.stereo_frames(20, 1, H=H, W=W).reshape(2, H, W)
@@ -172,6 +174,31 @@ def test_orient_rbrief_bit_exact(gpu, oracle, shape, max_kp):
     ang = torch.empty((2, max_kp), dtype=torch.uint8, device="cuda")
     L.call("vus_orient_rbrief", _dev(img).data_ptr(), _dev(blur).data_ptr(), 2, H, W, W,
            _dev(kp.view(np.int32)).data_ptr(), _dev(kc2).data_ptr(), max_kp, desc.data_ptr(), ang.data_ptr(),
+           L.current_stream_ptr())
+    torch.cuda.synchronize()
+    assert np.array_equal(ang.cpu().numpy(), eang)
+    assert np.array_equal(desc.cpu().numpy().view(np.uint64), edesc)
+
+
+def test_orient_rbrief_crowded_keypoints_and_duplicates(gpu, oracle):
+    """Hundreds of keypoints inside one 128 x 48 patch of the image (duplicates among them) and a second image with one
+    keypoint in each corner of such patches: keypoints of a wave's batch of eight share rows and lines."""
+    import visual_underwater_slam_amd._lib as L
+    H, W, K = 200, 400, 333
+    rng = np.random.default_rng(12)
+    img = rng.integers(0, 256, (2, H, W), dtype=np.uint8)
+    blur = oracle.blur7(img)
+    ys, xs = rng.integers(48, 96, K), rng.integers(128, 256, K)
+    kp = np.zeros((2, K), np.uint32)
+    kp[0] = (np.uint32(77) << 24) | (ys * W + xs).astype(np.uint32)
+    corners = [(y, x) for y in (0, 47, 48, 95, 96, 199) for x in (0, 127, 128, 255, 256, 399)]
+    kp[1, :len(corners)] = [(50 << 24) | (y * W + x) for y, x in corners]
+    kc = np.array([K, len(corners)], np.int32)
+    edesc, eang = oracle.orient_rbrief(img, blur, kp, kc)
+    desc = torch.empty((2, K, 4), dtype=torch.int64, device="cuda")
+    ang = torch.empty((2, K), dtype=torch.uint8, device="cuda")
+    L.call("vus_orient_rbrief", _dev(img).data_ptr(), _dev(blur).data_ptr(), 2, H, W, W,
+           _dev(kp.view(np.int32)).data_ptr(), _dev(kc).data_ptr(), K, desc.data_ptr(), ang.data_ptr(),
            L.current_stream_ptr())
     torch.cuda.synchronize()
     assert np.array_equal(ang.cpu().numpy(), eang)
