@@ -365,13 +365,14 @@ def main():
         "roofline": {"kernel": dom, "bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic,
                      "algorithmic_bytes_per_launch": ALGO_BYTES[dom] * n_proc,
-                     "note": "HBM reading of a kernel that is VALU-issue bound (see `valu`): traffic = FETCH_SIZE+WRITE_SIZE of "
+                     "note": "HBM reading of a kernel whose time goes into vector instructions and barrier waits, not into memory (see `valu`): traffic = FETCH_SIZE+WRITE_SIZE of "
                              "a separate rocprofv3 --pmc run (profiles/traffic.json), scaled to this launch"},
     }
     # every stage with its two readings: algorithmic bytes over the stage time against HBM, and -- where the committed PMC
     # summary has SQ_INSTS_VALU for its kernel -- vector wave-instructions over the stage time against the VALU issue peak
-    # (1.04 ns per wave-instruction per SIMD).  orient_rbrief: one wave per keypoint, ~230 vector instructions each; what
-    # it waits for is its own LDS round trips and the patch gather, neither HBM nor issue.
+    # (1.04 ns per wave-instruction per SIMD).  orient_rbrief: eight keypoints per wave, 117 vector instructions per keypoint
+    # (round 3: 232); what it waits for is the patch gather -- 92 L1 <- L2 line requests of 128 bytes per keypoint
+    # (profiles/pmc_orient_r04.txt), 0.77 ms of its 2.17 ms without them -- neither HBM (3.7 GB compulsory) nor issue.
     rs = {}
     for name in STAGES:
         b = ALGO_BYTES[name] * n_proc
@@ -401,7 +402,10 @@ def main():
             "measured_ms": round(stage_ms[dom], 3),
             "note": "SQ_INSTS_VALU (PMC, profiles/traffic.json) vs the VALU issue peak; the integer min/max/byte-select ops "
                     "of FAST issue at 0.57x the full rate on gfx950 (profiles/valu_issue_rates_*.txt), so frac ~0.65 of the "
-                    "full-rate peak IS this instruction mix's ceiling"}
+                    "full-rate peak is this instruction mix's ceiling.  Rounds 1-3 and the first adaptive detector sat at it "
+                    "(0.65-0.9); since the strip pre-test and the matrix-core smoothing of round 4 the kernel issues 0.82 M "
+                    "instead of 1.99 M vector instructions per image and a part of its time is waves parked at its five "
+                    "barriers (SQ_WAIT_ANY 52 % of the wave-cycles, profiles/pmc_frontend_r04.txt)"}
     # second bound, informational: the track matcher is an int8 GEMM on the matrix cores (2000 x 2000 x 256 multiply-
     # accumulates per image pair = the algorithmic work of brute-force Hamming matching in its dot-product form)
     mm_ops = 2.0 * (n_proc - 1) * KP * KP * 256

@@ -20,6 +20,8 @@ pmc sq2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONF
 pmc fetch FETCH_SIZE
 pmc write WRITE_SIZE
 python3 $ROOT/tools/summarize_pmc.py /tmp/pmc_sq1 /tmp/pmc_sq2 /tmp/pmc_fetch /tmp/pmc_write --traffic-json $OUT/traffic.json 400 > $OUT/pmc_frontend_${TAG}.txt || true
+# 3a. orient_rbrief_kernel alone: issue / wait split, LDS, L1 <- L2 requests of its patch gathers
+bash $ROOT/tools/pmc_orient.sh $OUT/pmc_orient_${TAG}.txt 200 || true
 # 3b. the 8-level pyramid mode (500 frames, 3 passes)
 rm -rf /tmp/prof_py && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_py -- python3 $ROOT/tools/pyramid_profile.py 500 > /dev/null 2>&1 || true
 python3 $ROOT/tools/summarize_stats.py /tmp/prof_py 40 | grep -v "at::native\|rocprim\|rocclr\|compute_cuda" > $OUT/kernel_stats_pyramid_${TAG}.txt || true
