@@ -310,19 +310,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pending = []
+
     def step():
         res = fe.process(images, check=False)
-        if world > 1:          # configs[3]: the step ends with the gather of the stream's feature-track records
-            vdist.gather_tracks(*vdist.owned_track_records(res, n_owned), n_stream, world, rank)
+        if world > 1:          # configs[3]: the step ends with the gather of the stream's feature-track records.  It is
+            # STARTED here (RCCL's own stream, records copied to a staging buffer) and awaited one step later, so that it
+            # overlaps the next step's kernels; drain() before every barrier: all K gathers end inside the timed region
+            pending.append(vdist.gather_tracks_start(*vdist.owned_track_records(res, n_owned), n_stream, world, rank))
+            while len(pending) > 1:
+                vdist.gather_tracks_finish(pending.pop(0))
+
+    def drain():
+        while pending:
+            vdist.gather_tracks_finish(pending.pop(0))
 
     # set-up pass (not a step): loads the code objects, validates that no image overflowed the candidate
     # buffer, and lets the clocks settle -- the first ~10 launches after an idle period run ~10 % slow
     for _ in range(8):
         step()
+    drain()
     barrier()
     fe.check_overflow()
     for _ in range(a.warmup):
         step()
+    drain()
     barrier()
     timer = StageTimer()
     fe.stage_hook = timer
@@ -330,6 +342,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(a.steps):
         step()
+    drain()
     barrier()
     dt = time.perf_counter() - t0
     fe.stage_hook = None

@@ -85,6 +85,26 @@ def test_gather_tracks_gloo_world2():
         assert np.array_equal(out[r][0], exp) and np.array_equal(out[r][1], exp + 1) and np.array_equal(out[r][2], exp + 2)
 
 
+def _gather_edge_worker(rank, world, n_frames, K):
+    """Records at the edges of the packed form: index -1 and K - 1 in both halves, keys with the top bit set."""
+    first, n_owned, _ = vdist.shard_frames(n_frames, world, rank)
+    g = torch.Generator().manual_seed(5)
+    st = torch.randint(-1, K, (n_frames, K), generator=g, dtype=torch.int32)
+    tr = torch.randint(-1, K, (n_frames, K), generator=g, dtype=torch.int32)
+    st[:, 0], tr[:, 0], st[:, 1], tr[:, 1] = -1, K - 1, K - 1, -1
+    ky = torch.randint(-2**31, 2**31 - 1, (n_frames, K), generator=g, dtype=torch.int64).to(torch.int32)
+    h = vdist.gather_tracks_start(st[first:first + n_owned], tr[first:first + n_owned], ky[first:first + n_owned], n_frames, world, rank)
+    a, b, c = vdist.gather_tracks_finish(h)
+    return bool(torch.equal(a, st) and torch.equal(b, tr) and torch.equal(c, ky)), h.packed
+
+
+def test_gather_tracks_packed_records_round_trip_gloo_world2():
+    """8 bytes per keypoint slot on the wire (two 16-bit indices + the key) up to K = 32767, three words beyond."""
+    for K, packed in ((2000, True), (32767, True), (40000, False)):
+        out = _run(_gather_edge_worker, 2, 3, K)
+        assert all(ok for ok, _ in out.values()) and all(p == packed for _, p in out.values())
+
+
 def _sharded_oracle_worker(rank, world, lam):
     """Each rank: oracle linearise + Schur on ITS landmarks, then the product's collectives."""
     from oracle import oracle as O

@@ -6,7 +6,8 @@ the two places where the path shards:
 
   front-end  frames are independent -> contiguous chunks of frames per rank with a one-frame halo so
              that every left(t)->left(t+1) pair is matched by exactly one rank; no collective on the
-             data path, one all_gather of the fixed-size per-frame match records at the end;
+             data path, one all_gather of the fixed-size per-frame match records at the end (8 B per
+             keypoint slot, started asynchronously: it overlaps the next batch's kernels);
   BA         landmarks are independent given the poses -> contiguous landmark ranges ("landmark
              block-rows") per rank, poses replicated.  Each rank linearises and eliminates its own
              landmarks; the exchange step is ONE reduce per lambda trial of the reduced camera system
@@ -36,30 +37,64 @@ def shard_frames(n_frames: int, world: int, rank: int, halo: int = 1) -> Tuple[i
     return first, n_owned, n_owned + n_halo
 
 
+class _TrackGather:
+    """An all_gather of feature-track records in flight (gather_tracks_start) and what finish() needs to unpack it."""
+    __slots__ = ("work", "bufs", "counts", "staged", "device", "packed")
+
+
+def gather_tracks_start(stereo_idx: torch.Tensor, track_idx: torch.Tensor, kp_keys_left: torch.Tensor,
+                        n_frames: int, world: int, rank: int) -> _TrackGather:
+    """Start the all_gather of the per-frame feature-track records (BASELINE.json configs[3]) and return at once: the
+    collective runs on RCCL's own stream, so the caller may launch the next step's kernels before gather_tracks_finish().
+    Inputs are this rank's owned rows: stereo_idx [n_owned, K], track_idx [n_owned, K] (row of the last frame of the
+    stream is all -1), kp_keys_left [n_owned, K]; they are copied into a staging buffer here and may be overwritten
+    afterwards.  One collective of 8 B per keypoint slot: the two match indices (-1 .. K - 1, K <= 32767) share one int32
+    word, the key is the second (16 KB per frame at K = 2000; with K > 32767 the three int32 records travel unpacked)."""
+    K = stereo_idx.shape[1]
+    h = _TrackGather()
+    h.counts = [shard_frames(n_frames, world, r)[1] for r in range(world)]
+    mx = max(h.counts)
+    n_own = stereo_idx.shape[0]
+    assert track_idx.shape[0] == n_own and kp_keys_left.shape[0] == n_own == h.counts[rank]
+    h.packed = K <= 32767
+    h.device = stereo_idx.device
+    if h.packed:
+        pad = torch.full((2, mx, K), -1, dtype=torch.int32, device=h.device)
+        pad[0, :n_own] = (stereo_idx.to(torch.int32) & 0xFFFF) | (track_idx.to(torch.int32) << 16)
+        pad[1, :n_own] = kp_keys_left.to(torch.int32)
+    else:
+        pad = torch.full((3, mx, K), -1, dtype=torch.int32, device=h.device)
+        pad[0, :n_own], pad[1, :n_own], pad[2, :n_own] = stereo_idx, track_idx, kp_keys_left.to(torch.int32)
+    h.work = None
+    if world > 1:
+        h.staged = pad.is_cuda and dist.get_backend() == "gloo"      # CPU rehearsal of the RCCL path
+        src = pad.cpu() if h.staged else pad
+        h.bufs = [torch.empty_like(src) for _ in range(world)]
+        h.work = dist.all_gather(h.bufs, src, async_op=True)
+    else:
+        h.staged = False
+        h.bufs = [pad]
+    return h
+
+
+def gather_tracks_finish(h: _TrackGather):
+    """Wait for the collective of gather_tracks_start() and return the three full [n_frames, K] int32 tensors."""
+    if h.work is not None:
+        h.work.wait()
+    bufs = [b.to(h.device) for b in h.bufs] if h.staged else h.bufs
+    if h.packed:
+        w0 = torch.cat([b[0, :c] for b, c in zip(bufs, h.counts)], 0)
+        keys = torch.cat([b[1, :c] for b, c in zip(bufs, h.counts)], 0)
+        stereo = (w0 << 16) >> 16            # sign-extending the low half restores -1
+        track = w0 >> 16                     # arithmetic shift: the high half keeps its sign
+        return stereo, track, keys
+    return tuple(torch.cat([b[t, :c] for b, c in zip(bufs, h.counts)], 0) for t in range(3))
+
+
 def gather_tracks(stereo_idx: torch.Tensor, track_idx: torch.Tensor, kp_keys_left: torch.Tensor,
                   n_frames: int, world: int, rank: int):
-    """all_gather of the per-frame feature-track records (BASELINE.json configs[3]).  Inputs are this
-    rank's owned rows: stereo_idx [n_owned, K], track_idx [n_owned, K] (row of the last frame of the
-    stream is all -1), kp_keys_left [n_owned, K].  Returns the three full [n_frames, K] tensors.
-    One collective: the three int32 records travel as one [3, rows, K] buffer (12 B per keypoint slot, 24 KB
-    per frame at K = 2000)."""
-    K = stereo_idx.shape[1]
-    counts = [shard_frames(n_frames, world, r)[1] for r in range(world)]
-    mx = max(counts)
-    n_own = stereo_idx.shape[0]
-    assert track_idx.shape[0] == n_own and kp_keys_left.shape[0] == n_own == counts[rank]
-    pad = torch.full((3, mx, K), -1, dtype=torch.int32, device=stereo_idx.device)
-    pad[0, :n_own], pad[1, :n_own], pad[2, :n_own] = stereo_idx, track_idx, kp_keys_left.to(torch.int32)
-    if world > 1:
-        staged = pad.is_cuda and dist.get_backend() == "gloo"      # CPU rehearsal of the RCCL path
-        src = pad.cpu() if staged else pad
-        bufs = [torch.empty_like(src) for _ in range(world)]
-        dist.all_gather(bufs, src)
-        if staged:
-            bufs = [b.to(pad.device) for b in bufs]
-    else:
-        bufs = [pad]
-    return tuple(torch.cat([b[t, :c] for b, c in zip(bufs, counts)], 0) for t in range(3))
+    """gather_tracks_start() + gather_tracks_finish(): the blocking form."""
+    return gather_tracks_finish(gather_tracks_start(stereo_idx, track_idx, kp_keys_left, n_frames, world, rank))
 
 
 def owned_track_records(res, n_owned: int):
