@@ -253,6 +253,14 @@ __device__ __forceinline__ void blur_tile_mfma(const uint32_t* s_img, uint8_t* _
   }
 }
 
+#ifdef VUS_FAST_DEBUG_COUNT   // counting build (tools/fast_counts.py): tiles, strips listed by pass 1a, pixels listed by pass 1b
+__device__ unsigned long long g_fast_dbg[4];
+extern "C" int vus_debug_fast_counters(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(g_fast_dbg), sizeof(g_fast_dbg)) != hipSuccess) return -1;
+  if (reset) { unsigned long long z[4] = {0, 0, 0, 0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_fast_dbg), z, sizeof(z)) != hipSuccess) return -1; }
+  return 0;
+}
+#endif
 // One 128 x 24 tile of image n.  HIST (with DETECT): the non-max-suppression survivors of the tile are not listed but
 // counted by score into hist[256 n + score] (vus_fast_threshold_estimate's sample).
 template <bool WRITE_SCORE, bool DETECT, bool BLUR, bool HIST = false>
@@ -348,6 +356,12 @@ __device__ __forceinline__ void fast_tile_body(
 #endif
   }
   __syncthreads();
+#ifdef VUS_FAST_EXIT_AFTER   // timing builds only (tools/ab): the kernel stops after phase N, results are wrong
+#define VUS_FAST_EXIT(N) do { if (VUS_FAST_EXIT_AFTER == (N)) return; } while (0)
+#else
+#define VUS_FAST_EXIT(N)
+#endif
+  VUS_FAST_EXIT(1);   // staging (+ per-dword extrema)
 
   if (WRITE_SCORE || DETECT) {
     // Pass 1 -- cheap necessary test on every pixel of the tile plus a ring (the 3x3 non-max
@@ -362,7 +376,8 @@ __device__ __forceinline__ void fast_tile_body(
     // (its N/S neighbours are bytes of the dwords above / below, its W/E neighbours lie in the dword to the left plus
     // the strip's first byte / the strip's last byte plus the dword to the right), or the mirrored condition on the
     // dark side.  Measured on the configs[1] frames: 9.0 % of the strips pass at the adaptive threshold where 8.2 % hold
-    // a pixel that passes the per-pixel test, 47 % against 45 % at fast_threshold 10.  The per-pixel test then runs on
+    // a pixel that passes the per-pixel test, 47 % against 45 % at fast_threshold 10 (single frames on the CPU; the counting
+    // build on the bench stream says 18.2 % of a tile's strips are listed and 3.9 % of its pixels pass pass 1b).  The per-pixel test then runs on
     // the listed strips only.
     // Thread = fixed strip column, S_RPP rows per pass (no per-item division; the LDS addresses of a pass differ from
     // the first one's by constants).  All passes are evaluated first and listed with ONE LDS atomic per wave.
@@ -411,7 +426,14 @@ __device__ __forceinline__ void fast_tile_body(
       }
     }
     __syncthreads();
+    VUS_FAST_EXIT(2);   // + strip pre-test
     const int nstrip = s_nstrip;
+#ifdef VUS_FAST_DEBUG_COUNT
+    if (tid == 0 && BLUR) { atomicAdd(&g_fast_dbg[0], 1ull); atomicAdd(&g_fast_dbg[1], (unsigned long long)nstrip); }
+#endif
+    // (Measured and not kept, round 4: the same test with one PIXEL per lane -- nine byte reads, no v_alignbyte / v_bfe,
+    // work spread over all four waves: bit-exact, 3.00 against 2.92 ms per 1000 stereo frames.  A tile lists 161 of its
+    // 884 strips here and 138 of their pixels go on to the exact score, tools/fast_counts.py.)
     for (int j0 = 0; j0 < nstrip; j0 += NTHREADS) {   // uniform trip count (wave scans inside)
       const int j = j0 + tid;
       int mask = 0, idx = 0;
@@ -501,9 +523,15 @@ __device__ __forceinline__ void fast_tile_body(
       *reinterpret_cast<uint2*>(&s_h[hr * H_DW + 2 * hs]) = out;
     }
   };
+#ifdef VUS_FAST_DEBUG_COUNT
+  __syncthreads();
+  if (tid == 0 && BLUR && (WRITE_SCORE || DETECT)) atomicAdd(&g_fast_dbg[2], (unsigned long long)s_nwork);
+#endif
+  VUS_FAST_EXIT(3);   // + per-pixel pre-test of the listed strips
   if (BLUR && !MFMA_BLUR && !STRIP) blur_rows();
   if (MFMA_BLUR) blur_tile_mfma(s_img, blur_out, n, H, W, x0, y0, tid);   // reads the staged tile only: no barrier of its own
   __syncthreads();
+  VUS_FAST_EXIT(4);   // + smoothing
 
   if (BLUR && !MFMA_BLUR && STRIP) blur_rows();   // after the barrier: its buffer held the strip tables until here
   if (WRITE_SCORE || DETECT) {
@@ -533,6 +561,7 @@ __device__ __forceinline__ void fast_tile_body(
     }
     __syncthreads();
   }
+  VUS_FAST_EXIT(5);   // + exact scores
 
   if (WRITE_SCORE) {
     for (int idx = tid; idx < TH * STRIPS; idx += NTHREADS) {
