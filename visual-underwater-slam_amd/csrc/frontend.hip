@@ -1997,8 +1997,11 @@ extern "C" int vus_fast_detect_adaptive(const uint8_t* img, int n_img, int H, in
   if (n_img == 0) return VUS_OK;
   hipStream_t st = vus::as_stream(stream);
   const TileGrid g = tile_grid(n_img, H, W);
+#ifndef VUS_FAST_LDS_PAD
+#define VUS_FAST_LDS_PAD 0   // occupancy experiment (tools/ab): dynamic LDS nobody uses = fewer workgroups per CU, same code
+#endif
   if (blur_out)
-    fast_tile_kernel<false, true, true><<<g.blocks, NTHREADS, 0, st>>>(
+    fast_tile_kernel<false, true, true><<<g.blocks, NTHREADS, VUS_FAST_LDS_PAD, st>>>(
         img, H, W, pitch, 0, thr_img, border, nullptr, blur_out, cand_keys, cand_cap, cand_count, n_img, g.tiles_x, g.tiles_per_img);
   else
     fast_tile_kernel<false, true, false><<<g.blocks, NTHREADS, 0, st>>>(
