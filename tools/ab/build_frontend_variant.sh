@@ -8,7 +8,7 @@ name=$1; flags=$2
 OFFLOAD=$(make -s print-offload)
 mkdir -p /tmp/tb_fe_$name
 rm -f "$HERE/libvus_fe_$name.so"
-/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC $OFFLOAD -Wno-unused-function -ffp-contract=off $flags -c frontend.hip -o /tmp/tb_fe_$name/frontend.o
+/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC $OFFLOAD -Wno-unused-function $(make -s print-frontend-flags) $flags -c frontend.hip -o /tmp/tb_fe_$name/frontend.o
 /opt/rocm/bin/hipcc -shared -fPIC $OFFLOAD vus_common.o /tmp/tb_fe_$name/frontend.o ba.o nav.o pack.o -o "$HERE/libvus_fe_$name.so"
-/opt/rocm/bin/hipcc -O3 -std=c++17 $OFFLOAD -ffp-contract=off $flags -S --cuda-device-only frontend.hip -o /tmp/tb_fe_$name/frontend.s 2>/dev/null
+/opt/rocm/bin/hipcc -O3 -std=c++17 $OFFLOAD $(make -s print-frontend-flags) $flags -S --cuda-device-only frontend.hip -o /tmp/tb_fe_$name/frontend.s 2>/dev/null
 grep -A30 "amdhsa_kernel _ZN12_GLOBAL__N_116fast_tile_kernelILb0ELb1ELb1EEE" /tmp/tb_fe_$name/frontend.s | grep -E "group_segment|next_free_vgpr|scratch" | tr -s '\t\n' ' '; echo " <- $name"

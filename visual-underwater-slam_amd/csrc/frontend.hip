@@ -1634,12 +1634,21 @@ __device__ __forceinline__ int spread_pm1(uint32_t nib) {
 constexpr int HM_QT = VUS_HM_QT;             // 32-query column tiles per wave (A fragments and the chunk expansion are shared)
 constexpr int HM_QWG = 4 * 32 * HM_QT;   // queries per workgroup
 
-// best key of one 32x32 tile for this lane's query: per value (dot << 5) | (31 - row) with the row as an
-// inline constant, a max3 tree, then one conversion to the global key (dot << 16) | (0xFFFF - train index)
+// 4 descriptor bits -> 4 bytes of +32 (bit set) / -32: the QUERY operand carries the factor 32 of the epilogue's key
+__device__ __forceinline__ int spread_pm32(uint32_t nib) {
+  const uint32_t sp = (nib * 0x00204081u) & 0x01010101u;
+  return (int)((sp * 0xC0u) ^ 0xE0E0E0E0u);
+}
+
+// best key of one 32x32 tile for this lane's query.  The accumulators ARE the keys (dot << 5) | (31 - row): the factor
+// 32 rides on the query operand (+-32 instead of +-1) and the row term is the accumulators' initial value (round 4: the
+// 32 v_lshl_or per tile that formed the keys were a third of the epilogue's vector instructions, and the epilogue, not the
+// matrix pipe, was the longer of the two per tile).  A max3 tree, then one conversion to the global key
+// (dot << 16) | (0xFFFF - train index).
 __device__ __forceinline__ int tile_best(const v16i_t& acc, int tb) {
   int k[16];
 #pragma unroll
-  for (int reg = 0; reg < 16; ++reg) k[reg] = acc[reg] * 32 + (31 - ((reg & 3) + 8 * (reg >> 2)));
+  for (int reg = 0; reg < 16; ++reg) k[reg] = acc[reg];
   const int m0 = max3i(k[0], k[1], k[2]), m1 = max3i(k[3], k[4], k[5]), m2 = max3i(k[6], k[7], k[8]),
             m3 = max3i(k[9], k[10], k[11]), m4 = max3i(k[12], k[13], k[14]);
   const int m = max(max3i(m0, m1, m2), max3i(m3, m4, k[15]));
@@ -1670,9 +1679,13 @@ __global__ __launch_bounds__(256) void hamming_match_mfma_kernel(const uint32_t*
     for (int ks = 0; ks < 8; ++ks) {
       const uint32_t bits = (q < nq ? dq[ks] : 0u) >> (16 * h);
 #pragma unroll
-      for (int n = 0; n < 4; ++n) bq[c][ks][n] = spread_pm1((bits >> (4 * n)) & 0xFu);
+      for (int n = 0; n < 4; ++n) bq[c][ks][n] = spread_pm32((bits >> (4 * n)) & 0xFu);
     }
   }
+  // initial value of a tile's accumulators: 31 - (row of the value inside this lane's sixteen), row = (reg & 3) + 8 (reg >> 2)
+  v16i_t cinit;
+#pragma unroll
+  for (int reg = 0; reg < 16; ++reg) cinit[reg] = 31 - ((reg & 3) + 8 * (reg >> 2));
   int best[HM_QT];
 #pragma unroll
   for (int c = 0; c < HM_QT; ++c) best[c] = INT_MIN;
@@ -1700,12 +1713,11 @@ __global__ __launch_bounds__(256) void hamming_match_mfma_kernel(const uint32_t*
       const uint8_t* arow = s_t + (32 * tile + r) * HM_ROWB + 16 * h;
       v16i_t acc[HM_QT];
 #pragma unroll
-      for (int c = 0; c < HM_QT; ++c) acc[c] = v16i_t{0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
         const v4i_t a = *reinterpret_cast<const v4i_t*>(arow + 32 * ks);
 #pragma unroll
-        for (int c = 0; c < HM_QT; ++c) acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[c][ks], acc[c], 0, 0, 0);
+        for (int c = 0; c < HM_QT; ++c)
+          acc[c] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, bq[c][ks], ks == 0 ? cinit : acc[c], 0, 0, 0);
       }
       const int tb = t0 + 32 * tile + 4 * h;            // train index of this lane's row 0
       if (t0 + 32 * tile + 32 > nt) {                   // wave-uniform: rows past the train count cannot win
@@ -1713,7 +1725,7 @@ __global__ __launch_bounds__(256) void hamming_match_mfma_kernel(const uint32_t*
         for (int reg = 0; reg < 16; ++reg)
           if (tb + (reg & 3) + 8 * (reg >> 2) >= nt) {
 #pragma unroll
-            for (int c = 0; c < HM_QT; ++c) acc[c][reg] = -32768;
+            for (int c = 0; c < HM_QT; ++c) acc[c][reg] = -(1 << 20);
           }
       }
 #pragma unroll
