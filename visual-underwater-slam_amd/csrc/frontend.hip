@@ -955,7 +955,6 @@ __device__ __forceinline__ uint32_t writelane_u32(uint32_t reg, uint32_t value, 
   return reg;
 }
 
-__device__ const uint8_t kDiscUmax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
 
 // Rotated test pattern re-laid for the kernel: [bin][lane][word] = the two patch byte offsets
 // (y * row bytes + x, int16 each) of test 64 * word + lane.  Derived from VUS_RBRIEF_ROT at COMPILE time, so
@@ -986,6 +985,33 @@ static_assert(OR_VW == 2 && OR_KP_PER_WAVE == 8, "orient_rbrief_kernel is writte
 constexpr int OR_NV = OR_ROWS * (OR_DW / OR_VW);   // 155 dwordx2 vectors of a centroid patch
 constexpr int OR_WT = 192;                         // weight entries per byte alignment: one per vector, padded to 3 x 64 lanes
 
+// The disc weights of orient_rbrief_kernel's s_w as a compile-time table: entry (sh, t) = weights of patch vector t (row
+// t / 5, dword pair t % 5) for a patch whose first column sits sh bytes into its first dword: .x/.y = (dx + 15) inside
+// the disc else 0 (u8 x 4) of the two dwords, .z/.w = 1 inside the disc else 0.
+struct DiscWeightTable {
+  uint32_t v[4 * OR_WT * 4];
+};
+constexpr DiscWeightTable make_disc_weight_table() {
+  constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+  DiscWeightTable r{};
+  for (int e = 0; e < 4 * OR_WT; ++e) {
+    const int sh = e / OR_WT, t = e - sh * OR_WT;
+    if (t >= OR_NV) continue;
+    const int row = t / (OR_DW / 2), c = t - row * (OR_DW / 2);
+    const int dy = row - OR_R, um = umax[dy < 0 ? -dy : dy];
+    for (int d = 0; d < 2; ++d)
+      for (int b = 0; b < 4; ++b) {
+        const int dx = 4 * (2 * c + d) + b - sh - OR_R;
+        if (dx >= -um && dx <= um) {
+          r.v[4 * e + d] |= (uint32_t)(dx + OR_R) << (8 * b);
+          r.v[4 * e + 2 + d] |= 1u << (8 * b);
+        }
+      }
+  }
+  return r;
+}
+__device__ __attribute__((aligned(16))) const DiscWeightTable g_disc_weight_table = make_disc_weight_table();
+
 // One wave = eight consecutive keypoints of one image, in two phases.
 //  A. orientation of all eight: the 31-row image patches arrive in registers (3 dwordx2 per lane and keypoint, up to
 //     12 in flight) and are multiplied right there with the disc weights (v_dot4_u32_u8; the weights of a lane's two
@@ -1013,24 +1039,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
   const int n = (slot / chunks_per_img) * 8 + xcd;
   const int chunk = slot - (slot / chunks_per_img) * chunks_per_img;
   if (n >= n_img) return;
-  for (int e = threadIdx.x; e < 4 * OR_WT; e += 256) {
-    const int sh = e / OR_WT, t = e - sh * OR_WT;
-    uint32_t w[4] = {0, 0, 0, 0};
-    if (t < OR_NV) {
-      const int r = t / (OR_DW / 2), c = t - r * (OR_DW / 2);
-      const int dy = r - OR_R, um = kDiscUmax[dy < 0 ? -dy : dy];
+  {   // the disc weights: a compile-time table, copied (deriving them per workgroup cost ~19 vector instructions per keypoint)
+    const uint4* wt = reinterpret_cast<const uint4*>(g_disc_weight_table.v);
 #pragma unroll
-      for (int d = 0; d < 2; ++d)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          const int dx = 4 * (2 * c + d) + b - sh - OR_R;
-          if (dx >= -um && dx <= um) {
-            w[d] |= (uint32_t)(dx + OR_R) << (8 * b);
-            w[2 + d] |= 1u << (8 * b);
-          }
-        }
-    }
-    s_w[e] = make_uint4(w[0], w[1], w[2], w[3]);
+    for (int i = 0; i < 4 * OR_WT / 256; ++i) s_w[threadIdx.x + 256 * i] = wt[threadIdx.x + 256 * i];
   }
   const uint8_t* im = img + (size_t)n * H * pitch;
   const uint8_t* bl = blur + (size_t)n * H * W;
