@@ -74,9 +74,12 @@ int vus_fast_detect(const uint8_t* img, int n_img, int H, int W, int pitch, int 
  * above it.  Detection at any per-image threshold thr_img[n] <= s* therefore selects the SAME keypoints as detection at
  * thr, while far fewer pixels reach the exact score.  Three calls, all asynchronous, no host decision in between:
  *   vus_fast_threshold_estimate  hist [n_img,256] (scratch, zeroed here): the survivors of a SAMPLE of the 128 x 24-pixel
- *       tiles (raster order, every sample_stride-th starting at tile sample_stride / 2), detected at thr, counted by
- *       score; thr_img[n] = the largest t in (thr, 254] with  count(score >= t) * tiles * VUS_FAST_MARGIN_DEN  >=
- *       max_kp * sampled tiles * VUS_FAST_MARGIN_NUM,  else thr.
+ *       tiles (raster order, every sample_stride-th starting at tile sample_stride / 2), counted by score; with
+ *       f = max(thr, VUS_FAST_SAMPLE_FLOOR):  thr_img[n] = the largest t in (f, 254] with
+ *       count(score >= t) * tiles * VUS_FAST_MARGIN_DEN  >=  max_kp * sampled tiles * VUS_FAST_MARGIN_NUM,  else thr.
+ *       The sample itself is detected at f: survivors with a score >= f are the same as at thr (a neighbour below f
+ *       cannot suppress them), so the bins from f on are what a detection at thr yields; the bins below f stay zero.
+ *       (An image whose estimate would lie in (thr, f] is detected at thr: slower, same keypoints.)
  *   vus_fast_detect_adaptive     vus_fast_detect with the per-image thresholds (device array).
  *   vus_fast_detect_retry        the check: every image with thr_img[n] > thr and cand_count[n] < max_kp (the estimate
  *       was too high: s* may lie below thr_img[n]) is detected again at thr -- cand_count[n] reset, candidates
@@ -84,6 +87,7 @@ int vus_fast_detect(const uint8_t* img, int n_img, int H, int W, int pitch, int 
  * After the three calls vus_select_topk gives exactly what it gives after vus_fast_detect(thr): bit-identical keys. */
 #define VUS_FAST_MARGIN_NUM 3
 #define VUS_FAST_MARGIN_DEN 2
+#define VUS_FAST_SAMPLE_FLOOR 40
 #define VUS_FAST_TILE_W 128
 #define VUS_FAST_TILE_H 24
 int vus_fast_threshold_estimate(const uint8_t* img, int n_img, int H, int W, int pitch, int thr, int border, int max_kp,

@@ -155,6 +155,7 @@ int vus_fast_threshold_estimate_cpu(const uint8_t* img, int n_img, int H, int W,
   long long n_sampled = (n_tiles - sample_stride / 2 + sample_stride - 1) / sample_stride;
   if (n_sampled < 1) n_sampled = 1;
   const int cap = H * W;                     /* every pixel could be a candidate */
+  const int floor = thr > VUS_FAST_SAMPLE_FLOOR ? thr : VUS_FAST_SAMPLE_FLOOR;
   for (int n = 0; n < n_img; ++n) {
     uint32_t* keys = (uint32_t*)malloc(sizeof(uint32_t) * (size_t)cap);
     int cnt = 0;
@@ -165,16 +166,18 @@ int vus_fast_threshold_estimate_cpu(const uint8_t* img, int n_img, int H, int W,
     for (int i = 0; i < cnt; ++i) {
       const int pos = (int)(keys[i] & ((1u << VUS_KEY_POS_BITS) - 1u)), sc = 255 - (int)(keys[i] >> VUS_KEY_POS_BITS);
       const int tile = (pos / W / VUS_FAST_TILE_H) * tx + (pos % W) / VUS_FAST_TILE_W;
-      if (tile >= sample_stride / 2 && (tile - sample_stride / 2) % sample_stride == 0) ++h[sc];
+      /* include/vus.h: only the bins from f = max(thr, VUS_FAST_SAMPLE_FLOOR) on are counted (the survivors at or above f
+       * of this detection at thr are the survivors of a detection at f) and only the bins above f can carry the estimate */
+      if (sc >= floor && tile >= sample_stride / 2 && (tile - sample_stride / 2) % sample_stride == 0) ++h[sc];
     }
     free(keys);
     long long run = 0;
     int t = 254;
-    for (; t > thr; --t) {
+    for (; t > floor; --t) {
       run += h[t];
       if (run * n_tiles * VUS_FAST_MARGIN_DEN >= (long long)max_kp * n_sampled * VUS_FAST_MARGIN_NUM) break;
     }
-    thr_img[n] = t;
+    thr_img[n] = t > floor ? t : thr;
   }
   return VUS_OK;
 }
