@@ -44,7 +44,7 @@ class ImageProcessorParams:
                                    # of the exact-score work.  Applies wherever a global top-K follows (single level, or
                                    # every pyramid level with its quota); grid bucketing needs every candidate: off there
     fast_sample_stride: int = 32   # every 32nd 128 x 24 tile is sampled (3 % of the image: ~90 survivors decide, 3.9 sigma
-                                   # from a wrong answer at the 1.5x margin -- and a wrong answer only costs that image a retry)
+                                   # from a wrong answer at the 1.75x margin -- and a wrong answer only costs that image a retry)
 
 
 def pyramid_layout(H: int, W: int, max_features: int, n_levels: int, scale_factor: float):
