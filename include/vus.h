@@ -122,6 +122,19 @@ int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_img, int H,
                       const uint32_t* kp_keys, const int* kp_count, int max_kp,
                       uint64_t* desc_out, uint8_t* angle_out, void* stream);
 
+/* The same outputs with the keypoints of an image SCHEDULED in a spatially coherent order (the patch gathers of
+ * neighbouring keypoints share cache lines while they are in flight: ~9 % off the kernel's time at 2000 keypoints per
+ * 1280 x 720 image).  vus_orient_order: order int32 [n_img, max_kp] = a permutation of every image's slots that groups the
+ * keypoints [0, kp_count) by 64 x 64-pixel cell, cells in raster order (WHICH permutation inside a cell is unspecified;
+ * slots from kp_count on map to themselves); images of more than 1024 cells are rejected (call vus_orient_rbrief).
+ * vus_orient_rbrief_ordered: slot s is served with keypoint order[s]; desc_out / angle_out are indexed by keypoint as in
+ * vus_orient_rbrief -- bit-identical outputs for ANY permutation that fixes the unused slots. */
+int vus_orient_order(const uint32_t* kp_keys, const int* kp_count, int n_img, int max_kp, int H, int W, int* order,
+                     void* stream);
+int vus_orient_rbrief_ordered(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
+                              const uint32_t* kp_keys, const int* kp_count, int max_kp, const int* order,
+                              uint64_t* desc_out, uint8_t* angle_out, void* stream);
+
 /* ---- optional ORB scale pyramid (ImageProcessorParams.n_levels > 1; Rublee et al. 2011, sec. 6.1:
  * 8 levels, scale 1.2).  Level l is resized from level l-1; detection, top-K (per-level quota) and
  * description run on every level with the calls above (H, W, pitch of that level); the per-level

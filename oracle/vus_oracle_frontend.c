@@ -317,6 +317,39 @@ int vus_oracle_tables_cpu(int which, int8_t* rot, int32_t* cosq, int32_t* sinq) 
 
 int vus_orient_rbrief_cpu(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
                           const uint32_t* kp_keys, const int* kp_count, int max_kp,
+                          uint64_t* desc_out, uint8_t* angle_out);
+
+/* Twins of vus_orient_order / vus_orient_rbrief_ordered (include/vus.h).  The order is a schedule of the GPU kernel, not
+ * arithmetic: any permutation that fixes the unused slots is a valid answer of the first (here: the identity) and the
+ * second gives vus_orient_rbrief's outputs whatever the permutation -- after checking that it is one. */
+int vus_orient_order_cpu(const uint32_t* kp_keys, const int* kp_count, int n_img, int max_kp, int H, int W, int* order) {
+  if (!kp_keys || !kp_count || !order || n_img < 0 || max_kp < 1 || H < 1 || W < 1) return VUS_E_INVALID;
+  for (int n = 0; n < n_img; ++n)
+    for (int j = 0; j < max_kp; ++j) order[(size_t)n * max_kp + j] = j;
+  return VUS_OK;
+}
+
+int vus_orient_rbrief_ordered_cpu(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
+                                  const uint32_t* kp_keys, const int* kp_count, int max_kp, const int* order,
+                                  uint64_t* desc_out, uint8_t* angle_out) {
+  if (!order || !kp_count || max_kp < 1) return VUS_E_INVALID;
+  for (int n = 0; n < n_img; ++n) {
+    const int cnt = kp_count[n] < max_kp ? kp_count[n] : max_kp;
+    uint8_t* seen = (uint8_t*)calloc((size_t)max_kp, 1);
+    int ok = seen != NULL;
+    for (int j = 0; ok && j < max_kp; ++j) {
+      const int o = order[(size_t)n * max_kp + j];
+      if (o < 0 || o >= max_kp || seen[o] || (j >= cnt && o != j) || (j < cnt && o >= cnt)) ok = 0;
+      else seen[o] = 1;
+    }
+    free(seen);
+    if (!ok) return VUS_E_INVALID;
+  }
+  return vus_orient_rbrief_cpu(img, blur, n_img, H, W, pitch, kp_keys, kp_count, max_kp, desc_out, angle_out);
+}
+
+int vus_orient_rbrief_cpu(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
+                          const uint32_t* kp_keys, const int* kp_count, int max_kp,
                           uint64_t* desc_out, uint8_t* angle_out) {
   if (!img || !blur || !kp_keys || !kp_count || !desc_out || !angle_out) return VUS_E_INVALID;
   oracle_tables_init();

@@ -180,6 +180,44 @@ def test_orient_rbrief_bit_exact(gpu, oracle, shape, max_kp):
     assert np.array_equal(desc.cpu().numpy().view(np.uint64), edesc)
 
 
+@pytest.mark.parametrize("shape,max_kp", [((160, 224), 300), ((720, 1280), 2000), ((97, 203), 120)])
+def test_orient_rbrief_in_cell_order_is_the_same_result(gpu, oracle, shape, max_kp):
+    """vus_orient_order groups an image's keypoints by 64 x 64 cell (a permutation that fixes the unused slots);
+    vus_orient_rbrief_ordered serves the slots in that order -- and in ANY such order -- with bit-identical outputs."""
+    import visual_underwater_slam_amd._lib as L
+    H, W = shape
+    img = synth.stereo_frames(21, 1, H=H, W=W).reshape(2, H, W)
+    kp, kc, blur, _, _ = _pipeline_oracle(oracle, img, max_kp)
+    kc2 = kc.copy()
+    kc2[1] = min(kc2[1], 37)     # a partly filled last batch of eight, then unused slots
+    edesc, eang = oracle.orient_rbrief(img, blur, kp, kc2)
+    d_kp, d_kc = _dev(kp.view(np.int32)), _dev(kc2)
+    order = torch.full((2, max_kp), -7, dtype=torch.int32, device="cuda")
+    L.call("vus_orient_order", d_kp.data_ptr(), d_kc.data_ptr(), 2, max_kp, H, W, order.data_ptr(), L.current_stream_ptr())
+    torch.cuda.synchronize()
+    o = order.cpu().numpy()
+    cw = (W + 63) // 64
+    for n in range(2):
+        c = int(kc2[n])
+        assert sorted(o[n, :c].tolist()) == list(range(c)) and np.array_equal(o[n, c:], np.arange(c, max_kp))
+        pos = (kp[n, o[n, :c]] & 0xFFFFFF).astype(np.int64)
+        cell = (pos // W // 64) * cw + (pos % W) // 64
+        assert np.all(np.diff(cell) >= 0), "keypoints are not grouped by cell in raster order"
+    rng = np.random.default_rng(3)
+    shuffled = o.copy()
+    for n in range(2):
+        c = int(kc2[n])
+        shuffled[n, :c] = rng.permutation(c)
+    for perm in (o, shuffled):
+        desc = torch.full((2, max_kp, 4), -1, dtype=torch.int64, device="cuda")
+        ang = torch.full((2, max_kp), 99, dtype=torch.uint8, device="cuda")
+        L.call("vus_orient_rbrief_ordered", _dev(img).data_ptr(), _dev(blur).data_ptr(), 2, H, W, W, d_kp.data_ptr(), d_kc.data_ptr(),
+               max_kp, _dev(perm).data_ptr(), desc.data_ptr(), ang.data_ptr(), L.current_stream_ptr())
+        torch.cuda.synchronize()
+        assert np.array_equal(ang.cpu().numpy(), eang)
+        assert np.array_equal(desc.cpu().numpy().view(np.uint64), edesc)
+
+
 def test_orient_rbrief_crowded_keypoints_and_duplicates(gpu, oracle):
     """Hundreds of keypoints inside one 128 x 48 patch of the image (duplicates among them) and a second image with one
     keypoint in each corner of such patches: keypoints of a wave's batch of eight share rows and lines."""

@@ -19,6 +19,8 @@ SIGNATURES = {
     "vus_fast_detect_retry": [_P, c_int, c_int, c_int, c_int, c_int, _P, c_int, c_int, _P, c_int, _P, _P, _P, _P],
     "vus_select_topk": [_P, _P, c_int, c_int, c_int, _P, _P, _P],
     "vus_orient_rbrief": [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P],
+    "vus_orient_order": [_P, _P, c_int, c_int, c_int, c_int, _P, _P],
+    "vus_orient_rbrief_ordered": [_P, _P, c_int, c_int, c_int, c_int, _P, _P, c_int, _P, _P, _P, _P],
     "vus_hamming_match": [_P, _P, _P, c_int, c_int, c_int, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],
     "vus_triangulate": [_P, c_int, _P, _P, _P, _P],
     "vus_select_grid": [_P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P],

@@ -1041,10 +1041,64 @@ __device__ __attribute__((aligned(16))) const DiscWeightTable g_disc_weight_tabl
 //     next keypoint's rows and its bin's test offsets are in flight meanwhile), 8 byte reads + 4 compares per lane; the
 //     ballots are written into lanes 4k + w of one register pair, so the eight descriptors leave in ONE 256-byte store.
 // Round 4 first pass: one keypoint at a time, 232 vector instructions per keypoint (2.67 ms per 1000 stereo frames).
-template <bool EXACT>
+// One workgroup per image: the image's keypoints counting-sorted by 64 x 64-pixel cell (cells in raster order; inside a
+// cell as the atomics fall -- a schedule, not a result).  order [n_img][max_kp]; slots from the image's count on map to
+// themselves.
+constexpr int OO_CELL = 64, OO_MAX_CELLS = 1024;
+__global__ __launch_bounds__(256) void orient_order_kernel(const uint32_t* __restrict__ kp_keys, const int* __restrict__ kp_count,
+                                                           int max_kp, int W, int cw, int n_cells, int* __restrict__ order) {
+  __shared__ int s_cnt[OO_MAX_CELLS];
+  __shared__ int s_wave[4];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int cnt = min(kp_count[n], max_kp);
+  const uint32_t* keys = kp_keys + (size_t)n * max_kp;
+  int* ord = order + (size_t)n * max_kp;
+  for (int r = tid; r < n_cells; r += 256) s_cnt[r] = 0;
+  __syncthreads();
+  for (int j = tid; j < cnt; j += 256) {
+    const uint32_t pos = keys[j] & VUS_KEY_POS_MASK;
+    const int y = (int)(pos / (uint32_t)W), x = (int)(pos - (uint32_t)y * (uint32_t)W);
+    atomicAdd(&s_cnt[(y / OO_CELL) * cw + (x / OO_CELL)], 1);
+  }
+  __syncthreads();
+  int c[4], sum = 0;      // exclusive scan of the <= 1024 counts: four consecutive cells per thread
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    c[q] = 4 * tid + q < n_cells ? s_cnt[4 * tid + q] : 0;
+    sum += c[q];
+  }
+  int incl = sum;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(incl, d);
+    if ((tid & 63) >= d) incl += o;
+  }
+  if ((tid & 63) == 63) s_wave[tid >> 6] = incl;
+  __syncthreads();
+  int base = incl - sum;
+  for (int w = 0; w < (tid >> 6); ++w) base += s_wave[w];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    if (4 * tid + q < n_cells) {
+      s_cnt[4 * tid + q] = base;   // becomes the cell's fill cursor
+      base += c[q];
+    }
+  __syncthreads();
+  for (int j = tid; j < cnt; j += 256) {
+    const uint32_t pos = keys[j] & VUS_KEY_POS_MASK;
+    const int y = (int)(pos / (uint32_t)W), x = (int)(pos - (uint32_t)y * (uint32_t)W);
+    ord[atomicAdd(&s_cnt[(y / OO_CELL) * cw + (x / OO_CELL)], 1)] = j;
+  }
+  for (int j = cnt + tid; j < max_kp; j += 256) ord[j] = j;
+}
+
+// ORDERED: slot s of an image is served with keypoint order[s] (vus_orient_order: the image's keypoints grouped by 64 x 64
+// cell, the unused slots mapped to themselves), so that the eight keypoints of a wave and the 32 of a workgroup are
+// neighbours and their patch rows share lines in flight; the outputs go to the keypoint's own index.  A schedule only.
+template <bool EXACT, bool ORDERED>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE, 8))) void orient_rbrief_kernel(
     const uint8_t* __restrict__ img, const uint8_t* __restrict__ blur, int H, int W, int pitch,
-    const uint32_t* __restrict__ kp_keys, const int* __restrict__ kp_count, int max_kp,
+    const uint32_t* __restrict__ kp_keys, const int* __restrict__ kp_count, int max_kp, const int* __restrict__ order,
     uint64_t* __restrict__ desc_out, uint8_t* __restrict__ angle_out, int n_img, int chunks_per_img) {
   // centroid weights per patch vector (two dwords), for the 4 possible byte alignments of the patch:
   // .x/.y = (dx + 15) inside the disc else 0 (u8 x 4) of the two dwords, .z/.w = 1 inside the disc else 0
@@ -1069,8 +1123,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
   const int base_i = (chunk * 4 + wave) * OR_KP_PER_WAVE;       // this wave's keypoints: base_i .. base_i + 7
   const int n_live = clampi(min(kp_count[n], max_kp) - base_i, 0, OR_KP_PER_WAVE);
   int my_y = 0, my_x = 0;                                         // lane k < 8: position of keypoint k
+  int my_idx = base_i + lane;                                     // ... and its index in the image's list
+  if (ORDERED && lane < OR_KP_PER_WAVE && base_i + lane < max_kp) my_idx = order[(size_t)n * max_kp + base_i + lane];
   if (lane < n_live) {
-    const uint32_t pos = kp_keys[(size_t)n * max_kp + base_i + lane] & VUS_KEY_POS_MASK;
+    const uint32_t pos = kp_keys[(size_t)n * max_kp + my_idx] & VUS_KEY_POS_MASK;
     my_y = (int)(pos / (uint32_t)W);
     my_x = (int)(pos - (uint32_t)my_y * (uint32_t)W);
   }
@@ -1169,7 +1225,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
     best = allmax8_i64(best);
     my_bin = 31 - (int)(best & 31);   // a keypoint that is not live has zero moments: bin 0
   }
-  if ((lane & 7) == 0 && base_i + (lane >> 3) < max_kp) angle_out[(size_t)n * max_kp + base_i + (lane >> 3)] = (uint8_t)my_bin;
+  {
+    const int j_ang = ORDERED ? __shfl(my_idx, lane >> 3) : base_i + (lane >> 3);
+    if ((lane & 7) == 0 && base_i + (lane >> 3) < max_kp) angle_out[(size_t)n * max_kp + j_ang] = (uint8_t)my_bin;
+  }
 
   // ---- phase B: the descriptors
   uint32_t wlo = 0, whi = 0;   // lane 4k + w: word w of keypoint k
@@ -1200,8 +1259,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(VUS_OR_WPE,
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
   }
+  const int j_desc = ORDERED ? __shfl(my_idx, lane >> 2) : 0;   // keypoint k's index lives in lane k; lanes 4k .. 4k+3 store its words
   if (lane < 4 * OR_KP_PER_WAVE && base_i + (lane >> 2) < max_kp)
-    desc_out[((size_t)n * max_kp + base_i) * 4 + lane] = ((uint64_t)whi << 32) | wlo;
+    desc_out[ORDERED ? ((size_t)n * max_kp + j_desc) * 4 + (lane & 3) : ((size_t)n * max_kp + base_i) * 4 + lane] =
+        ((uint64_t)whi << 32) | wlo;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2098,9 +2159,8 @@ extern "C" int vus_select_topk(const uint32_t* cand_keys, const int* cand_count,
   return VUS_OK;
 }
 
-extern "C" int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
-                                 const uint32_t* kp_keys, const int* kp_count, int max_kp,
-                                 uint64_t* desc_out, uint8_t* angle_out, void* stream) {
+static int orient_launch(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch, const uint32_t* kp_keys,
+                         const int* kp_count, int max_kp, const int* order, uint64_t* desc_out, uint8_t* angle_out, void* stream) {
   if (int rc = check_image_args(img, n_img, H, W, pitch)) return rc;
   VUS_REQUIRE(blur && kp_keys && kp_count && desc_out && angle_out, "null buffer");
   VUS_REQUIRE(max_kp >= 1, "max_kp=%d", max_kp);
@@ -2111,14 +2171,44 @@ extern "C" int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_
   // rows of both planes on dword boundaries -> aligned patch loads; otherwise exact-start (unaligned) loads
   const bool aligned = ((reinterpret_cast<uintptr_t>(img) | reinterpret_cast<uintptr_t>(blur) | (uintptr_t)pitch |
                          (uintptr_t)W | ((uintptr_t)H * (uintptr_t)pitch)) & 3u) == 0;
-  if (aligned)
-    orient_rbrief_kernel<false><<<(unsigned)blocks, 256, 0, vus::as_stream(stream)>>>(
-        img, blur, H, W, pitch, kp_keys, kp_count, max_kp, desc_out, angle_out, n_img, chunks);
-  else
-    orient_rbrief_kernel<true><<<(unsigned)blocks, 256, 0, vus::as_stream(stream)>>>(
-        img, blur, H, W, pitch, kp_keys, kp_count, max_kp, desc_out, angle_out, n_img, chunks);
+#define VUS_OR_LAUNCH(EX, ORD)                                                                              \
+  orient_rbrief_kernel<EX, ORD><<<(unsigned)blocks, 256, 0, vus::as_stream(stream)>>>(                      \
+      img, blur, H, W, pitch, kp_keys, kp_count, max_kp, order, desc_out, angle_out, n_img, chunks)
+  if (aligned && order) VUS_OR_LAUNCH(false, true);
+  else if (aligned) VUS_OR_LAUNCH(false, false);
+  else if (order) VUS_OR_LAUNCH(true, true);
+  else VUS_OR_LAUNCH(true, false);
+#undef VUS_OR_LAUNCH
   VUS_CHECK_LAUNCH("orient_rbrief");
   return VUS_OK;
+}
+
+extern "C" int vus_orient_rbrief(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
+                                 const uint32_t* kp_keys, const int* kp_count, int max_kp,
+                                 uint64_t* desc_out, uint8_t* angle_out, void* stream) {
+  return orient_launch(img, blur, n_img, H, W, pitch, kp_keys, kp_count, max_kp, nullptr, desc_out, angle_out, stream);
+}
+
+extern "C" int vus_orient_order(const uint32_t* kp_keys, const int* kp_count, int n_img, int max_kp, int H, int W, int* order,
+                                void* stream) {
+  VUS_REQUIRE(kp_keys && kp_count && order, "null buffer");
+  VUS_REQUIRE(n_img >= 0 && max_kp >= 1 && H >= 1 && W >= 1, "n_img=%d max_kp=%d H=%d W=%d", n_img, max_kp, H, W);
+  if (n_img == 0) return VUS_OK;
+  // cells of 64 x 64 pixels; an image with more than 1024 of them gets coarser cells (the order is a schedule: any
+  // grouping is valid)
+  int cw = (W + OO_CELL - 1) / OO_CELL, ch = (H + OO_CELL - 1) / OO_CELL;
+  VUS_REQUIRE((long long)cw * ch <= OO_MAX_CELLS, "image of %d x %d pixels has more than %d cells of %d x %d", W, H, OO_MAX_CELLS,
+              OO_CELL, OO_CELL);
+  orient_order_kernel<<<n_img, 256, 0, vus::as_stream(stream)>>>(kp_keys, kp_count, max_kp, W, cw, cw * ch, order);
+  VUS_CHECK_LAUNCH("orient_order");
+  return VUS_OK;
+}
+
+extern "C" int vus_orient_rbrief_ordered(const uint8_t* img, const uint8_t* blur, int n_img, int H, int W, int pitch,
+                                         const uint32_t* kp_keys, const int* kp_count, int max_kp, const int* order,
+                                         uint64_t* desc_out, uint8_t* angle_out, void* stream) {
+  VUS_REQUIRE(order != nullptr, "null buffer");
+  return orient_launch(img, blur, n_img, H, W, pitch, kp_keys, kp_count, max_kp, order, desc_out, angle_out, stream);
 }
 
 extern "C" int vus_hamming_match(const uint64_t* desc, const uint32_t* kp_keys, const int* kp_count,

@@ -140,6 +140,9 @@ class StereoOrbFrontend:
         self.kp_count = torch.zeros((n_img,), dtype=torch.int32, device=dev)
         self.desc = torch.empty((n_img, K, 4), dtype=torch.int64, device=dev)
         self.angle = torch.empty((n_img, K), dtype=torch.uint8, device=dev)
+        # the schedule of the orientation + rBRIEF launch: every image's keypoint slots grouped by 64 x 64-pixel cell
+        # (vus_orient_order; a schedule only -- outputs are indexed by keypoint); images of more than 1024 cells go unordered
+        self.kp_order = torch.empty((n_img, K), dtype=torch.int32, device=dev)
         # rows [0, F): stereo pairs; rows [max_frames, max_frames + F - 1): temporal pairs
         self.match_idx = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
         self.match_dist = torch.empty((2 * self.max_frames, K), dtype=torch.int32, device=dev)
@@ -214,8 +217,8 @@ class StereoOrbFrontend:
                 _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, K,
                           ptr(self.kp_keys), ptr(self.kp_count), st)
             mark("select_topk")
-            _lib.call("vus_orient_rbrief", ptr(images), ptr(self.blur), n_img, H, W, W, ptr(self.kp_keys),
-                      ptr(self.kp_count), K, ptr(self.desc), ptr(self.angle), st)
+            self._orient(ptr(images), ptr(self.blur), n_img, H, W, ptr(self.kp_keys), ptr(self.kp_count), K, ptr(self.desc),
+                         ptr(self.angle), st)
             mark("orient_rbrief")
         else:
             self._process_pyramid(images, n_img, st)
@@ -277,11 +280,20 @@ class StereoOrbFrontend:
             torch.maximum(self.pyr_cand_max, self.cand_count[:n_img].max().reshape(1), out=self.pyr_cand_max)
             _lib.call("vus_select_topk", ptr(self.cand_keys), ptr(self.cand_count), n_img, p.cand_cap, L["quota"],
                       ptr(L["keys"]), ptr(L["count"]), st)
-            _lib.call("vus_orient_rbrief", ptr(prev), ptr(L["blur"]), n_img, h, w, w, ptr(L["keys"]), ptr(L["count"]),
-                      L["quota"], ptr(L["desc"]), ptr(L["angle"]), st)
+            self._orient(ptr(prev), ptr(L["blur"]), n_img, h, w, ptr(L["keys"]), ptr(L["count"]), L["quota"], ptr(L["desc"]),
+                         ptr(L["angle"]), st)
             _lib.call("vus_pyramid_append", ptr(L["keys"]), ptr(L["count"]), ptr(L["desc"]), ptr(L["angle"]), n_img,
                       L["quota"], h, w, l, self.H, self.W, K, ptr(self.kp_keys), ptr(self.kp_count), ptr(self.desc),
                       ptr(self.angle), ptr(self.kp_level), ptr(self.kp_xy_q4), st)
+
+    def _orient(self, img_p, blur_p, n_img, h, w, keys_p, count_p, k, desc_p, angle_p, st):
+        """Orientation + rBRIEF of n_img images of h x w pixels with k keypoint slots each, in the cell-grouped order."""
+        if ((h + 63) // 64) * ((w + 63) // 64) <= 1024:
+            _lib.call("vus_orient_order", keys_p, count_p, n_img, k, h, w, _lib.ptr(self.kp_order), st)
+            _lib.call("vus_orient_rbrief_ordered", img_p, blur_p, n_img, h, w, w, keys_p, count_p, k, _lib.ptr(self.kp_order),
+                      desc_p, angle_p, st)
+        else:
+            _lib.call("vus_orient_rbrief", img_p, blur_p, n_img, h, w, w, keys_p, count_p, k, desc_p, angle_p, st)
 
     def check_overflow(self, n_img=None):
         """Raises if any image since the last check produced more FAST candidates than cand_cap (one device
