@@ -208,6 +208,10 @@ __device__ __forceinline__ void blur_tile_mfma(const uint32_t* s_img, uint8_t* _
   const long bv[2] = {(long)g_blur_mfma_table.v[0][l], (long)g_blur_mfma_table.v[1][l]};
   const uint8_t* img8 = reinterpret_cast<const uint8_t*>(s_img);
   constexpr unsigned long long SIGN = 0x8080808080808080ull;
+#ifndef VUS_BLUR_UNROLL
+#define VUS_BLUR_UNROLL 1
+#endif
+#pragma unroll VUS_BLUR_UNROLL
   for (int j = tid >> 6; j < TW / 16; j += NTHREADS / 64) {
     v4i32_t ch[2];
 #pragma unroll
@@ -239,6 +243,9 @@ __device__ __forceinline__ void blur_tile_mfma(const uint32_t* s_img, uint8_t* _
       for (int r = 0; r < 4; ++r) q[r] = ((uint32_t)chi[r] << 8) + (uint32_t)clo[r];   // < 2^24: the pixel is byte 2
       const uint32_t v = __builtin_amdgcn_perm(q[1], q[0], 0x0c0c0602u) | __builtin_amdgcn_perm(q[3], q[2], 0x06020c0cu);
       const int ly = 16 * nb + m, gy = y0 + ly, gx = x0 + 16 * j + 4 * g;
+#ifdef VUS_BLUR_EXP_NOSTORE   // timing experiment: everything but the stores (a value nobody produces keeps the result live)
+      if (v != 0x12345678u) continue;
+#endif
       if (ly < TH && gy < H) {
         uint8_t* o = blur_out + ((size_t)n * H + gy) * W + gx;
         if (gx + 3 < W) {
