@@ -370,8 +370,9 @@ def main():
         "config": {"workload": "configs[1]: stereo ORB detect+match, 1280x720, 2000 kpts/image, "
                                f"{F}-frame stream per GPU resident in HBM, single pyramid level",
                    "frames_per_gpu": F, "keypoints_per_image": KP, "fast_threshold": 10,
-                   "parallelism": (f"frames sharded x{world} (+1 halo frame per shard), all_gather of the feature-track "
-                                   f"records inside the step" if world > 1 else "1 GPU, no collective")},
+                   "parallelism": (f"frames sharded x{world} (+1 halo frame per shard); all_gather of the feature-track records "
+                                   f"(8 B per keypoint slot) started at the end of every step on RCCL's stream and awaited one "
+                                   f"step later, all of them inside the timed region" if world > 1 else "1 GPU, no collective")},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
         "fast_detect_parts_ms": fast_parts,
         "pipeline_GBps": round(ALGO_BYTES_FRAME * F * a.steps / dt / 1e9 * world, 2),
