@@ -65,6 +65,13 @@ def test_invalid_arguments_are_rejected_without_a_gpu():
     rc = lib.vus_select_topk(ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 10, 100000, ctypes.c_void_p(8),
                              ctypes.c_void_p(8), None)
     assert rc == -1 and b"max_kp" in lib.vus_last_error()
+    # the cell-grouped schedule keeps its histogram in LDS: an image of more than 1024 cells of 64 x 64 pixels is refused
+    # (callers use vus_orient_rbrief for those), a missing order is refused by the scheduled launch
+    rc = lib.vus_orient_order(ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 100, 4096, 4096, ctypes.c_void_p(8), None)
+    assert rc == -1 and b"cells" in lib.vus_last_error()
+    rc = lib.vus_orient_rbrief_ordered(ctypes.c_void_p(8), ctypes.c_void_p(8), 1, 64, 64, 64, ctypes.c_void_p(8), ctypes.c_void_p(8), 10,
+                                       None, ctypes.c_void_p(8), ctypes.c_void_p(8), None)
+    assert rc == -1 and b"null" in lib.vus_last_error()
 
 
 def test_product_never_imports_the_oracle():
