@@ -160,6 +160,9 @@ __device__ __forceinline__ bool nms_keep(const uint32_t (&c)[3][3]) {
 #ifndef VUS_BLUR_MFMA
 #define VUS_BLUR_MFMA 1   // the 7x7 smoothing as two banded int8 GEMMs on the matrix cores (see blur_tile_mfma)
 #endif
+#ifndef VUS_FAST_MM_BYTES
+#define VUS_FAST_MM_BYTES 1   // pass 1a reads the (min, max) pairs as bytes: 3.01 -> 2.96 ms per 1000 stereo frames
+#endif
 #ifndef VUS_FAST_DIAG
 #define VUS_FAST_DIAG 1   // pre-test also on the two diagonal opposite pairs: survivors 33 % -> 25 %, 6.32 -> 6.23 ms
 #endif
@@ -404,6 +407,16 @@ __device__ __forceinline__ void fast_tile_body(
         const int gy = y0 - 1 + sr;
         if (col_ok && gy >= 3 && gy < H - 3) {
           const int ci = ci0 + it * S_RPP * IMG_DW;
+#if VUS_FAST_MM_BYTES   // the (min, max) pairs read as the two bytes they are: ten ds_read_u8 instead of five ds_read_u16 + shifts / masks
+          const uint8_t* mm8 = reinterpret_cast<const uint8_t*>(s_mm) + 2 * ci;
+          const int ma_lo = mm8[0], ma_hi = mm8[1], pmin = mm8[2], pmax = mm8[3], mc_lo = mm8[4], mc_hi = mm8[5];
+          const int mn_lo = mm8[2 - 6 * IMG_DW], mn_hi = mm8[3 - 6 * IMG_DW], ms_lo = mm8[2 + 6 * IMG_DW], ms_hi = mm8[3 + 6 * IMG_DW];
+          const uint32_t b = s_img[ci + 1];
+          const int b0 = byte_of(b, 0), b3 = byte_of(b, 3);
+          const int hi = min(max(mn_hi, ms_hi), max3i(ma_hi, mc_hi, max(b0, b3)));
+          const int lo = max(min(mn_lo, ms_lo), min3i(ma_lo, mc_lo, min(b0, b3)));
+          pass[it] = hi > pmin + thr || lo < pmax - thr;
+#else
           const int ma = s_mm[ci], mb = s_mm[ci + 1], mc = s_mm[ci + 2];
           const int mn = s_mm[ci + 1 - 3 * IMG_DW], ms = s_mm[ci + 1 + 3 * IMG_DW];
           const uint32_t b = s_img[ci + 1];
@@ -412,6 +425,7 @@ __device__ __forceinline__ void fast_tile_body(
           const int hi = min(max(mn >> 8, ms >> 8), max3i(ma >> 8, mc >> 8, max(b0, b3)));
           const int lo = max(min(mn & 0xFF, ms & 0xFF), min3i(ma & 0xFF, mc & 0xFF, min(b0, b3)));
           pass[it] = hi > pmin + thr || lo < pmax - thr;
+#endif
         }
         s_score[sr * SC_DW + ss] = 0u;
       }
