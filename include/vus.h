@@ -80,7 +80,12 @@ int vus_fast_detect(const uint8_t* img, int n_img, int H, int W, int pitch, int 
  *       The sample itself is detected at f: survivors with a score >= f are the same as at thr (a neighbour below f
  *       cannot suppress them), so the bins from f on are what a detection at thr yields; the bins below f stay zero.
  *       (An image whose estimate would lie in (thr, f] is detected at thr: slower, same keypoints.)
- *   vus_fast_detect_adaptive     vus_fast_detect with the per-image thresholds (device array).
+ *   vus_fast_detect_adaptive     vus_fast_detect with the per-image thresholds (device array).  With blur_out and
+ *       cand_cap >= 512 the list of an image is filled as eight sub-lists (tile t into sub-list t mod 8, counters in the
+ *       row itself) and compacted by a second launch before the call returns its work to the stream: cand_count[n] must
+ *       be ZERO on entry (it is overwritten with the total), the result is the usual compact list in unspecified order;
+ *       a sub-list that outgrows cand_cap / 8 - 1 entries is reported as an overflow of the list (cand_count[n] >
+ *       cand_cap, the unwritten tail = VUS_KEY_INVALID).
  *   vus_fast_detect_retry        the check: every image with thr_img[n] > thr and cand_count[n] < max_kp (the estimate
  *       was too high: s* may lie below thr_img[n]) is detected again at thr -- cand_count[n] reset, candidates
  *       rewritten; blur_out of the adaptive pass stays valid.  retry_list [n_img] scratch, retry_count[0] = how many.

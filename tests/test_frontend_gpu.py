@@ -466,6 +466,39 @@ def test_adaptive_detector_selects_the_same_keypoints_as_fast_threshold(gpu, ora
     assert np.array_equal(_u32(fe.kp_keys[:6]), kp) and np.array_equal(cnt, kc)
 
 
+def test_adaptive_detection_sublists_compact_and_report_overflow(gpu, oracle):
+    """vus_fast_detect_adaptive fills an image's candidate list as eight sub-lists and compacts them: with room, the
+    list is the oracle's candidate SET and cand_count its size; when a sub-list outgrows cand_cap / 8 - 1 the call
+    reports an overflow (cand_count > cand_cap), every key it kept is a true candidate and the tail is VUS_KEY_INVALID."""
+    import visual_underwater_slam_amd._lib as L
+    H, W = 360, 640
+    imgs = _adaptive_images(H, W)[:3]
+    n = len(imgs)
+    d_img = torch.from_numpy(imgs).cuda()
+    thr_img = torch.tensor([12, 10, 30][:n], dtype=torch.int32, device="cuda")
+    blur = torch.empty((n, H, W), dtype=torch.uint8, device="cuda")
+    st = L.current_stream_ptr()
+    want = []
+    for i in range(n):
+        ok, oc, _ = oracle.fast_detect(imgs[i:i + 1], int(thr_img[i]), 31, H * W, want_blur=False)
+        want.append(set(ok[0, :int(oc[0])].tolist()))
+    for cap in (H * W, 512):
+        keys = torch.full((n, cap), 123, dtype=torch.int32, device="cuda")
+        cnt = torch.zeros((n,), dtype=torch.int32, device="cuda")
+        L.call("vus_fast_detect_adaptive", d_img.data_ptr(), n, H, W, W, thr_img.data_ptr(), 31, blur.data_ptr(), keys.data_ptr(), cap,
+               cnt.data_ptr(), st)
+        torch.cuda.synchronize()
+        k, c = _u32(keys), cnt.cpu().numpy()
+        for i in range(n):
+            if cap == H * W:
+                assert c[i] == len(want[i]) and set(k[i, :c[i]].tolist()) == want[i]
+            elif len(want[i]) > cap // 8 - 1:      # more than one sub-list can hold: at least one of them overflowed here
+                assert c[i] > cap, "overflow of a sub-list must be reported as an overflow of the list"
+                valid = k[i][k[i] != 0xFFFFFFFF]
+                assert len(valid) == len(set(valid.tolist())) and set(valid.tolist()) <= want[i] and len(valid) >= cap // 8 - 1
+                assert np.all(k[i, len(valid):] == 0xFFFFFFFF) and np.all(k[i, :len(valid)] != 0xFFFFFFFF)
+
+
 def test_adaptive_detector_check_catches_a_wrong_estimate(gpu, oracle):
     """vus_fast_detect_retry IS the guarantee: with thresholds far too high for every image (250), all of them fail the
     count check, are listed and detected again at fast_threshold -- the candidates of vus_fast_detect, exactly."""

@@ -184,6 +184,10 @@ __device__ __forceinline__ bool nms_keep(const uint32_t (&c)[3][3]) {
 #ifndef VUS_BLUR_MFMA
 #define VUS_BLUR_MFMA 1   // the 7x7 smoothing as two banded int8 GEMMs on the matrix cores (see blur_tile_mfma)
 #endif
+#ifndef VUS_FAST_LATE_BLUR
+#define VUS_FAST_LATE_BLUR 1
+#endif
+constexpr int VUS_CAND_REGIONS = 8;
 #ifndef VUS_FAST_SCORE_BYTES
 #define VUS_FAST_SCORE_BYTES 1   // exact score from 17 byte reads around the pixel (2.92 -> 2.89 ms per 1000 stereo frames)
 #endif
@@ -230,8 +234,10 @@ constexpr BlurMfmaTable make_blur_mfma_table() {
 __device__ __attribute__((aligned(16))) const BlurMfmaTable g_blur_mfma_table = make_blur_mfma_table();
 typedef int v4i32_t __attribute__((ext_vector_type(4)));
 
+// The tile's eight 16-column blocks go to the waves j_first, j_first + j_step, ... (all four waves: tid >> 6, 4; the
+// late form below: three waves, the fourth waits for the tile's global atomic meanwhile).
 __device__ __forceinline__ void blur_tile_mfma(const uint32_t* s_img, uint8_t* __restrict__ blur_out, int n, int H, int W,
-                                               int x0, int y0, int tid) {
+                                               int x0, int y0, int tid, int j_first, int j_step) {
   static_assert(IMG_ROWS == 32 && TW % 16 == 0 && (IMG_DW * 4) % 8 == 0, "blur_tile_mfma: K = the 32 staged rows");
   const int l = tid & 63, g = l >> 4, m = l & 15;
   const long bh = (long)g_blur_mfma_table.h[l];
@@ -242,7 +248,7 @@ __device__ __forceinline__ void blur_tile_mfma(const uint32_t* s_img, uint8_t* _
 #define VUS_BLUR_UNROLL 1
 #endif
 #pragma unroll VUS_BLUR_UNROLL
-  for (int j = tid >> 6; j < TW / 16; j += NTHREADS / 64) {
+  for (int j = j_first; j < TW / 16; j += j_step) {
     v4i32_t ch[2];
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
@@ -300,7 +306,7 @@ extern "C" int vus_debug_fast_counters(unsigned long long* out, int reset) {
 #endif
 // One 128 x 24 tile of image n.  HIST (with DETECT): the non-max-suppression survivors of the tile are not listed but
 // counted by score into hist[256 n + score] (vus_fast_threshold_estimate's sample).
-template <bool WRITE_SCORE, bool DETECT, bool BLUR, bool HIST = false>
+template <bool WRITE_SCORE, bool DETECT, bool BLUR, bool HIST = false, bool REGIONS = false>
 __device__ __forceinline__ void fast_tile_body(
     const uint8_t* __restrict__ img, int H, int W, int pitch, int thr, int border,
     uint8_t* __restrict__ score_out, uint8_t* __restrict__ blur_out,
@@ -321,9 +327,14 @@ __device__ __forceinline__ void fast_tile_body(
   __shared__ int s_nstrip;
 #endif
   __shared__ int s_cnt, s_base, s_nwork;
-  // the candidate list reuses the image tile, which is dead after the second barrier
+  // LATE_BLUR (the detection launch proper): the smoothing runs at the END of the tile, on three waves, while the fourth
+  // waits for the returning atomic that reserves the tile's slots in the image's candidate list.  The staged image then
+  // has to live to the end: the candidate list moves to the strip tables' buffer (dead after pass 1b).  Otherwise the
+  // list reuses the image tile, dead after the exact scores.
+  constexpr bool LATE_BLUR = MFMA_BLUR && DETECT && !HIST && STRIP && VUS_FAST_LATE_BLUR;
   static_assert(IMG_ROWS * IMG_DW >= TW * TH / 4, "candidate list must fit in the image tile");
-  uint32_t* const s_keys = s_img;
+  static_assert(!LATE_BLUR || AUX_DW >= TW * TH / 4, "candidate list must fit in the strip tables' buffer");
+  uint32_t* const s_keys = LATE_BLUR ? s_h : s_img;
 
   const int tid = threadIdx.x;
   const int x0 = (tile % tiles_x) * TW, y0 = (tile / tiles_x) * TH;
@@ -577,7 +588,7 @@ __device__ __forceinline__ void fast_tile_body(
 #endif
   VUS_FAST_EXIT(3);   // + per-pixel pre-test of the listed strips
   if (BLUR && !MFMA_BLUR && !STRIP) blur_rows();
-  if (MFMA_BLUR) blur_tile_mfma(s_img, blur_out, n, H, W, x0, y0, tid);   // reads the staged tile only: no barrier of its own
+  if (MFMA_BLUR && !LATE_BLUR) blur_tile_mfma(s_img, blur_out, n, H, W, x0, y0, tid, tid >> 6, NTHREADS / 64);   // reads the staged tile only: no barrier of its own
   __syncthreads();
   VUS_FAST_EXIT(4);   // + smoothing
 
@@ -687,12 +698,24 @@ __device__ __forceinline__ void fast_tile_body(
     if (!HIST) {
       __syncthreads();
       const int cnt = s_cnt;
-      if (tid == 0 && cnt > 0) s_base = atomicAdd(&cand_count[n], cnt);
+      // REGIONS: the image's list is filled as VUS_CAND_REGIONS sub-lists, tile t into region t mod 8, each with its counter in
+      // its own first slot (cand_region_merge_kernel compacts them afterwards): the ~300 returning atomics of an image on
+      // ONE word serialised at the memory side -- 0.14 of the launch's 2.93 ms (timing build with eight counters on lines
+      // of their own)
+      const int rcap = cand_cap / VUS_CAND_REGIONS;
+      uint32_t* const list = cand_keys + (size_t)n * cand_cap + (REGIONS ? (size_t)(tile & (VUS_CAND_REGIONS - 1)) * rcap : 0);
+      int* const counter = REGIONS ? reinterpret_cast<int*>(list) : &cand_count[n];
+      if (LATE_BLUR) {
+        if (tid == NTHREADS - 64 && cnt > 0) s_base = atomicAdd(counter, cnt);
+        if (tid < NTHREADS - 64) blur_tile_mfma(s_img, blur_out, n, H, W, x0, y0, tid, tid >> 6, NTHREADS / 64 - 1);
+      } else {
+        if (tid == 0 && cnt > 0) s_base = atomicAdd(counter, cnt);
+      }
       __syncthreads();
       if (cnt > 0) {
-        const int base = s_base;
+        const int base = s_base + (REGIONS ? 1 : 0), lim = REGIONS ? rcap : cand_cap;
         for (int i = tid; i < cnt; i += NTHREADS)
-          if (base + i < cand_cap) cand_keys[(size_t)n * cand_cap + base + i] = s_keys[i];
+          if (base + i < lim) list[base + i] = s_keys[i];
       }
     }
   }
@@ -701,7 +724,7 @@ __device__ __forceinline__ void fast_tile_body(
 // XCD-aware block -> (image, tile) map: blocks with equal (blockIdx % 8) share an XCD, so all tiles of one
 // image run on ONE XCD and the halo re-reads of neighbouring tiles hit its L2 instead of HBM (speed only).
 // thr_img (may be null): per-image thresholds of the adaptive detector (vus_fast_detect_adaptive).
-template <bool WRITE_SCORE, bool DETECT, bool BLUR>
+template <bool WRITE_SCORE, bool DETECT, bool BLUR, bool REGIONS = false>
 __global__ __launch_bounds__(NTHREADS, VUS_FAST_WPE) void fast_tile_kernel(
     const uint8_t* __restrict__ img, int H, int W, int pitch, int thr, const int* __restrict__ thr_img, int border,
     uint8_t* __restrict__ score_out, uint8_t* __restrict__ blur_out,
@@ -711,8 +734,49 @@ __global__ __launch_bounds__(NTHREADS, VUS_FAST_WPE) void fast_tile_kernel(
   const int n = (slot / tiles_per_img) * 8 + xcd;
   if (n >= n_img) return;
   const int tile = slot - (slot / tiles_per_img) * tiles_per_img;
-  fast_tile_body<WRITE_SCORE, DETECT, BLUR>(img, H, W, pitch, thr_img ? thr_img[n] : thr, border, score_out, blur_out, cand_keys,
-                                            cand_cap, cand_count, nullptr, n, tile, tiles_x);
+  fast_tile_body<WRITE_SCORE, DETECT, BLUR, false, REGIONS>(img, H, W, pitch, thr_img ? thr_img[n] : thr, border, score_out, blur_out,
+                                                            cand_keys, cand_cap, cand_count, nullptr, n, tile, tiles_x);
+}
+
+// The regions of fast_tile_kernel<.., REGIONS>: counters zeroed before the launch ...
+__global__ void cand_region_zero_kernel(uint32_t* __restrict__ cand_keys, int cand_cap, int n_img) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_img * VUS_CAND_REGIONS)
+    cand_keys[(size_t)(t / VUS_CAND_REGIONS) * cand_cap + (size_t)(t % VUS_CAND_REGIONS) * (cand_cap / VUS_CAND_REGIONS)] = 0u;
+}
+
+// ... and compacted after it, one workgroup per image: region r's keys (slots 1 .. of its part of the row) move down to
+// where region r - 1's ended -- always to lower addresses than anything still unread, a chunk read whole before it is
+// written -- and cand_count[n] becomes the total.  A region that overflowed its share of cand_cap (the image's candidates
+// would have to sit in every eighth tile for that to happen below cand_cap) is reported as an overflow of the list:
+// cand_count[n] > cand_cap, the unwritten tail filled with VUS_KEY_INVALID.
+__global__ __launch_bounds__(256) void cand_region_merge_kernel(uint32_t* __restrict__ cand_keys, int cand_cap, int* __restrict__ cand_count) {
+  __shared__ int s_c[VUS_CAND_REGIONS];
+  const int n = blockIdx.x, tid = threadIdx.x;
+  const int rcap = cand_cap / VUS_CAND_REGIONS;
+  uint32_t* row = cand_keys + (size_t)n * cand_cap;
+  if (tid < VUS_CAND_REGIONS) s_c[tid] = (int)row[(size_t)tid * rcap];
+  __syncthreads();
+  int off = 0;
+  long long all = 0;
+  bool over = false;
+  for (int r = 0; r < VUS_CAND_REGIONS; ++r) {
+    const int c = s_c[r], m = min(c, rcap - 1);
+    all += c;
+    over |= c > rcap - 1;
+    const uint32_t* src = row + (size_t)r * rcap + 1;
+    for (int i0 = 0; i0 < m; i0 += 256) {
+      const int i = i0 + tid;
+      const uint32_t v = i < m ? src[i] : 0u;
+      __syncthreads();
+      if (i < m) row[off + i] = v;
+      __syncthreads();
+    }
+    off += m;
+  }
+  if (over)
+    for (int i = off + tid; i < cand_cap; i += 256) row[i] = VUS_KEY_INVALID;
+  if (tid == 0) cand_count[n] = over ? (int)max(all, (long long)cand_cap + 1) : off;
 }
 
 // ---- the adaptive detector (round 4): the top-K keypoints of an image depend only on pixels whose score reaches s*,
@@ -2162,7 +2226,14 @@ extern "C" int vus_fast_detect_adaptive(const uint8_t* img, int n_img, int H, in
 #ifndef VUS_FAST_LDS_PAD
 #define VUS_FAST_LDS_PAD 0   // occupancy experiment (tools/ab): dynamic LDS nobody uses = fewer workgroups per CU, same code
 #endif
-  if (blur_out)
+  // with room for it, the list is filled as eight sub-lists and compacted afterwards (fast_tile_body, REGIONS)
+  const bool regions = blur_out != nullptr && cand_cap >= 64 * VUS_CAND_REGIONS;
+  if (regions) {
+    cand_region_zero_kernel<<<(n_img * VUS_CAND_REGIONS + 255) / 256, 256, 0, st>>>(cand_keys, cand_cap, n_img);
+    fast_tile_kernel<false, true, true, true><<<g.blocks, NTHREADS, VUS_FAST_LDS_PAD, st>>>(
+        img, H, W, pitch, 0, thr_img, border, nullptr, blur_out, cand_keys, cand_cap, cand_count, n_img, g.tiles_x, g.tiles_per_img);
+    cand_region_merge_kernel<<<n_img, 256, 0, st>>>(cand_keys, cand_cap, cand_count);
+  } else if (blur_out)
     fast_tile_kernel<false, true, true><<<g.blocks, NTHREADS, VUS_FAST_LDS_PAD, st>>>(
         img, H, W, pitch, 0, thr_img, border, nullptr, blur_out, cand_keys, cand_cap, cand_count, n_img, g.tiles_x, g.tiles_per_img);
   else
